@@ -1,0 +1,78 @@
+"""ctypes binding of libpcdet_mi355.so (the C ABI declared in include/pcdet_mi355.h).
+
+The library is the product: if it cannot be loaded every op raises -- there is no CPU or PyTorch fallback.
+PyTorch only supplies device memory (tensor.data_ptr()) and the current HIP stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpcdet_mi355.so")
+
+PVX_OK = 0
+_ERR = {-1: "PVX_ERR_INVALID", -2: "PVX_ERR_WORKSPACE", -3: "PVX_ERR_HIP", -4: "PVX_ERR_RANGE"}
+PVX_F32, PVX_F16, PVX_BF16 = 0, 1, 2
+DTYPE_CODE = {torch.float32: PVX_F32, torch.float16: PVX_F16, torch.bfloat16: PVX_BF16}
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/pcdet_mi355.h declares
+SIGNATURES = {
+    "pvx_version": (ctypes.c_char_p, []),
+    "pvx_last_hip_error": (c_int, []),
+    "pvx_boxes_overlap_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "pvx_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "pvx_boxes_overlap_bev_paired": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pvx_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pvx_nms": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
+    "pvx_boxes_iou_bev_cpu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpcdet_mi355.so not found at %s -- build it with `python -m openpcdet_amd.build` "
+                "(there is no fallback path)" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != PVX_OK:
+        extra = ""
+        if rc == -3:
+            extra = " (hipError %d)" % lib().pvx_last_hip_error()
+        raise RuntimeError("%s failed: %s%s" % (what, _ERR.get(rc, str(rc)), extra))
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, None for None/empty."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return t.data_ptr() if t.numel() > 0 else None
+
+
+def stream(device=None):
+    """Raw hipStream_t of PyTorch's current stream (as an integer for ctypes c_void_p)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,311 @@
+// Rotated-BEV IoU matrices and greedy NMS for gfx950 (MI355X), plus the host-side CPU entry points.
+//
+// Replaces pcdet/ops/iou3d_nms/src/{iou3d_nms_kernel.cu, iou3d_nms.cpp, iou3d_cpu.cpp} behind the C ABI in
+// include/pcdet_mi355.h.  Design (DESIGN.md section "NMS"):
+//  * one 64-lane wavefront produces one 64-bit suppression word per row box with a single __ballot
+//    (lane = column box), so there is no per-thread bit loop and no shared-memory OR;
+//  * only upper-triangle 64x64 tiles do work (the reference launches all N^2/64^2 tiles, kernel.cu:303);
+//  * per-box trigonometry and corner rotation are done once per tile into LDS records, not once per pair;
+//  * the greedy scan runs on the device in one workgroup per problem, so neither the N x N/64 mask nor the
+//    keep list crosses PCIe (the reference copies the whole mask D2H and loops on the host,
+//    iou3d_nms.cpp:155-179);
+//  * many independent problems (heads x frames) go in one launch through a segment table.
+// Build flags for this TU: -ffp-contract=off (see iou_core.h).
+#include "pvx_common.h"
+#include "iou_core.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxColBlocks = 1024;   // n <= 65536 boxes per NMS problem
+
+// per-thread polygon vertex scratch in LDS, laid out [slot][thread] so lanes hit distinct banks
+struct VertexScratch {
+    float x[PVX_POLY_MAX * kBlock];
+    float y[PVX_POLY_MAX * kBlock];
+    float a[PVX_POLY_MAX * kBlock];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// [n, m] matrix of overlap areas (MODE 1) or IoUs (MODE 0).  Block = 16 rows x 64 columns; lane = column so
+// the 64 results of a wave-row are one coalesced 256-B store.
+// ---------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void bev_matrix_kernel(const float* __restrict__ a, int n,
+                                                             const float* __restrict__ b, int m,
+                                                             float* __restrict__ out) {
+    __shared__ PvxBoxRec colrec[64];
+    __shared__ PvxBoxRec rowrec[16];
+    __shared__ VertexScratch vs;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col0 = blockIdx.x * 64, row0 = blockIdx.y * 16;
+    if (tid < 64) {
+        if (col0 + tid < m) pvx_box_prepare(b + (size_t)(col0 + tid) * 7, colrec[tid]);
+    } else if (tid < 80) {
+        const int r = tid - 64;
+        if (row0 + r < n) pvx_box_prepare(a + (size_t)(row0 + r) * 7, rowrec[r]);
+    }
+    __syncthreads();
+    const int col = col0 + lane;
+    if (col >= m) return;
+    const PvxBoxRec B = colrec[lane];
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        const int row = row0 + wave * 4 + r;
+        if (row >= n) break;
+        const PvxBoxRec A = rowrec[wave * 4 + r];
+        float v = pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock);
+        if (MODE == 0) v = pvx_iou_from_overlap(A, B, v);
+        out[(size_t)row * m + col] = v;
+    }
+}
+
+// element-wise overlap area of a[i], b[i]
+__global__ __launch_bounds__(kBlock) void bev_paired_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             int n, float* __restrict__ out) {
+    __shared__ VertexScratch vs;
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    if (i >= n) return;
+    PvxBoxRec A, B;
+    pvx_box_prepare(a + (size_t)i * 7, A);
+    pvx_box_prepare(b + (size_t)i * 7, B);
+    out[i] = pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Suppression mask.  grid = (col tiles, row tiles, segments); tiles below the diagonal exit at once.
+// Wave w of the block owns rows 16w..16w+15 of the tile; for every row one ballot over the 64 column lanes
+// is the mask word (bit j <=> iou(row box, column box j) > thresh), exactly the word the reference's thread
+// builds with a 64-step loop (kernel.cu:325-337).  Only columns after the row are set on the diagonal tile
+// (kernel.cu:328-330).
+// ---------------------------------------------------------------------------------------------------
+template <int NORMAL>
+__global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                           int n_host, int n_cap, int cb_cap, float thresh,
+                                                           unsigned long long* __restrict__ mask) {
+    const int R = blockIdx.y, C = blockIdx.x, seg = blockIdx.z;
+    if (R > C) return;
+    int n = counts ? counts[seg] : n_host;
+    n = n < 0 ? 0 : (n > n_cap ? n_cap : n);
+    if (C * 64 >= n) return;   // R <= C, so the row tile is non-empty whenever the column tile is
+
+    __shared__ PvxBoxRec colrec[64];
+    __shared__ PvxBoxRec rowrec[64];
+    __shared__ float rawcol[64 * 7];
+    __shared__ float rawrow[64 * 7];
+    __shared__ VertexScratch vs;
+
+    const float* seg_boxes = boxes + (size_t)seg * n_cap * 7;
+    unsigned long long* seg_mask = mask + (size_t)seg * n_cap * cb_cap;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (tid < 128) {
+        const int t = tid & 63;
+        const int idx = (tid < 64 ? C : R) * 64 + t;
+        if (idx < n) {
+            const float* src = seg_boxes + (size_t)idx * 7;
+            if (NORMAL) {
+                float* dst = (tid < 64 ? rawcol : rawrow) + t * 7;
+#pragma unroll
+                for (int k = 0; k < 7; k++) dst[k] = src[k];
+            } else {
+                pvx_box_prepare(src, tid < 64 ? colrec[t] : rowrec[t]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int col = C * 64 + lane;
+    const bool col_ok = col < n;
+    PvxBoxRec B;
+    float braw[7];
+    if (col_ok) {
+        if (NORMAL) {
+#pragma unroll
+            for (int k = 0; k < 7; k++) braw[k] = rawcol[lane * 7 + k];
+        } else {
+            B = colrec[lane];
+        }
+    }
+#pragma unroll 1
+    for (int r = 0; r < 16; r++) {
+        const int rt = wave * 16 + r;          // row inside the tile (wave-uniform)
+        const int row = R * 64 + rt;
+        if (row >= n) break;                   // wave-uniform exit
+        bool bit = false;
+        if (col_ok && (R != C || lane > rt)) {
+            float v;
+            if (NORMAL) {
+                v = pvx_iou_normal(rawrow + rt * 7, braw);
+            } else {
+                const PvxBoxRec A = rowrec[rt];
+                v = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock));
+            }
+            bit = v > thresh;
+        }
+        const unsigned long long word = __ballot(bit);
+        if (lane == 0) seg_mask[(size_t)row * cb_cap + C] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Greedy scan, one workgroup per problem (device-side twin of iou3d_nms.cpp:163-179).
+// remv lives in LDS; per 64-box chunk wave 0 resolves the in-chunk dependency chain with the diagonal
+// words held one per lane (readlane), then all threads OR the kept rows into the later remv words.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                           const int* __restrict__ counts, int n_host, int n_cap,
+                                                           int cb_cap, long long* __restrict__ keep,
+                                                           int* __restrict__ num_keep) {
+    __shared__ unsigned long long remv[kMaxColBlocks];
+    __shared__ int kept_in_chunk[64];
+    __shared__ int kept_count;
+    const int seg = blockIdx.x;
+    int n = counts ? counts[seg] : n_host;
+    n = n < 0 ? 0 : (n > n_cap ? n_cap : n);
+    const int cb = PVX_CDIV(n, 64);
+    const unsigned long long* seg_mask = mask + (size_t)seg * n_cap * cb_cap;
+    long long* seg_keep = keep + (size_t)seg * n_cap;
+    const int tid = threadIdx.x;
+    for (int w = tid; w < cb; w += kBlock) remv[w] = 0ull;
+    int total = 0;
+    for (int c = 0; c < cb; c++) {
+        __syncthreads();   // remv[c] final; previous chunk's kept list consumed
+        if (tid < 64) {
+            const int row = c * 64 + tid;
+            const unsigned long long diag = row < n ? seg_mask[(size_t)row * cb_cap + c] : 0ull;
+            unsigned long long cur = remv[c];
+            unsigned long long kept = 0ull;
+            const int lim = (n - c * 64) < 64 ? (n - c * 64) : 64;
+            for (int k = 0; k < lim; k++) {
+                const unsigned long long dk = __shfl(diag, k);
+                if (!((cur >> k) & 1ull)) { kept |= 1ull << k; cur |= dk; }
+            }
+            if ((kept >> tid) & 1ull) {
+                const int pos = __popcll(kept & ((1ull << tid) - 1ull));
+                kept_in_chunk[pos] = tid;
+                seg_keep[total + pos] = (long long)row;
+            }
+            if (tid == 0) kept_count = __popcll(kept);
+        }
+        __syncthreads();
+        const int kc = kept_count;
+        total += kc;
+        for (int w = c + 1 + tid; w < cb; w += kBlock) {
+            unsigned long long acc = remv[w];
+            for (int q = 0; q < kc; q++) acc |= seg_mask[(size_t)(c * 64 + kept_in_chunk[q]) * cb_cap + w];
+            remv[w] = acc;
+        }
+    }
+    if (tid == 0) num_keep[seg] = total;
+}
+
+int check_boxes(const float* a, int n, const float* b, int m, const float* out) {
+    if (n < 0 || m < 0) return PVX_ERR_INVALID;
+    if ((n > 0 && !a) || (m > 0 && !b) || ((size_t)n * m > 0 && !out)) return PVX_ERR_INVALID;
+    return PVX_OK;
+}
+
+template <int MODE>
+int launch_matrix(const float* a, int n, const float* b, int m, float* out, void* stream) {
+    int rc = check_boxes(a, n, b, m, out);
+    if (rc != PVX_OK) return rc;
+    if (n == 0 || m == 0) return PVX_OK;
+    if (PVX_CDIV(n, 16) > 65535) return PVX_ERR_RANGE;
+    dim3 grid(PVX_CDIV(m, 64), PVX_CDIV(n, 16));
+    hipLaunchKernelGGL(bev_matrix_kernel<MODE>, grid, dim3(kBlock), 0, (hipStream_t)stream, a, n, b, m, out);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+}  // namespace
+
+extern "C" int pvx_boxes_overlap_bev(const float* a, int n, const float* b, int m, float* out, void* stream) {
+    return launch_matrix<1>(a, n, b, m, out, stream);
+}
+
+extern "C" int pvx_boxes_iou_bev(const float* a, int n, const float* b, int m, float* out, void* stream) {
+    return launch_matrix<0>(a, n, b, m, out, stream);
+}
+
+extern "C" int pvx_boxes_overlap_bev_paired(const float* a, const float* b, int n, float* out, void* stream) {
+    if (n < 0 || (n > 0 && (!a || !b || !out))) return PVX_ERR_INVALID;
+    if (n == 0) return PVX_OK;
+    hipLaunchKernelGGL(bev_paired_kernel, dim3(PVX_CDIV(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, a, b, n, out);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" size_t pvx_nms_workspace_bytes(int n_cap, int segments) {
+    if (n_cap <= 0 || segments <= 0) return 256;
+    PvxSizer s;
+    s.take<unsigned long long>((size_t)segments * n_cap * PVX_CDIV(n_cap, 64));
+    return s.total();
+}
+
+extern "C" int pvx_nms_batched(const float* boxes, const int* counts, int segments, int n_cap, float thresh, int normal,
+                               int64_t* keep, int* num_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (segments < 0 || n_cap < 0 || !num_keep) return PVX_ERR_INVALID;
+    if (segments == 0) return PVX_OK;
+    if (segments > 65535) return PVX_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_cap == 0) {
+        PVX_CHECK_HIP(hipMemsetAsync(num_keep, 0, sizeof(int) * segments, st));
+        return PVX_OK;
+    }
+    if (!boxes || !keep) return PVX_ERR_INVALID;
+    const int cb_cap = PVX_CDIV(n_cap, 64);
+    if (cb_cap > kMaxColBlocks) return PVX_ERR_RANGE;
+    PvxCarver ws(workspace, workspace_bytes);
+    unsigned long long* mask = ws.take<unsigned long long>((size_t)segments * n_cap * cb_cap);
+    if (!ws.ok() || !mask) return PVX_ERR_WORKSPACE;
+    dim3 grid(cb_cap, cb_cap, segments);
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(segments), dim3(kBlock), 0, st, mask, counts, n_cap, n_cap, cb_cap,
+                       (long long*)keep, num_keep);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0) return PVX_ERR_INVALID;
+    return pvx_nms_batched(boxes, nullptr, 1, n, thresh, normal, keep, num_keep, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host (CPU) entry points: same arithmetic through iou_core.h's host path (libm cosf/sinf/atan2f).
+// ---------------------------------------------------------------------------------------------------
+extern "C" int pvx_boxes_iou_bev_cpu(const float* a, int n, const float* b, int m, float* out) {
+    int rc = check_boxes(a, n, b, m, out);
+    if (rc != PVX_OK) return rc;
+    PvxBoxRec* rb = m > 0 ? new PvxBoxRec[m] : nullptr;
+    for (int j = 0; j < m; j++) pvx_box_prepare(b + (size_t)j * 7, rb[j]);
+    float vx[PVX_POLY_MAX], vy[PVX_POLY_MAX], va[PVX_POLY_MAX];
+    for (int i = 0; i < n; i++) {
+        PvxBoxRec A;
+        pvx_box_prepare(a + (size_t)i * 7, A);
+        for (int j = 0; j < m; j++)
+            out[(size_t)i * m + j] = pvx_iou_from_overlap(A, rb[j], pvx_overlap(A, rb[j], vx, vy, va, 1));
+    }
+    delete[] rb;
+    return PVX_OK;
+}
+
+extern "C" int pvx_boxes_aligned_iou_bev_cpu(const float* a, const float* b, int n, float* out) {
+    if (n < 0 || (n > 0 && (!a || !b || !out))) return PVX_ERR_INVALID;
+    float vx[PVX_POLY_MAX], vy[PVX_POLY_MAX], va[PVX_POLY_MAX];
+    for (int i = 0; i < n; i++) {
+        PvxBoxRec A, B;
+        pvx_box_prepare(a + (size_t)i * 7, A);
+        pvx_box_prepare(b + (size_t)i * 7, B);
+        out[i] = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vx, vy, va, 1));
+    }
+    return PVX_OK;
+}
