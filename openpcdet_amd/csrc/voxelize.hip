@@ -1,0 +1,315 @@
+// Hard (first-come, capped) voxelization + fused mean VFE on gfx950.
+//
+// Replaces, on the device, the CPU voxelizer the reference calls inside its DataLoader workers
+// (VoxelGeneratorWrapper -> spconv.utils.Point2VoxelCPU3d.point_to_voxel,
+//  pcdet/datasets/processor/data_processor.py:16-61, 200-247) and MeanVFE.forward
+// (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-33).  Semantics: SURVEY.md 8a-1 / oracle/voxel_oracle.c.
+//
+// The CPU algorithm is sequential ("first come": voxel ids in order of first appearance, the first T points
+// of a voxel in input order, cells first seen after max_voxels ids were given are dropped).  The parallel
+// formulation that reproduces it bit-for-bit, independent of thread timing:
+//   1. insert   every in-range point CASes its 64-bit cell key into an open-addressing table in HBM
+//               (linear probing, load factor <= 0.5) and atomicMin's its own index into the slot, so every
+//               occupied slot ends up knowing the FIRST point of its cell;
+//   2. rank     point i is a "first point" iff first[slot(i)] == i.  A wavefront ballot + popcount prefix
+//               (block sums scanned by one workgroup) ranks the first points in input order: that rank IS
+//               the sequential voxel id.  Cells with rank >= max_voxels are exactly the ones the sequential
+//               algorithm refuses;
+//   3. bucket   every point of a kept cell pushes its index through an atomicMin cascade over the cell's T
+//               slots; whatever the arrival order, slot t ends up holding the (t+1)-th smallest point index;
+//   4. gather   one thread per (voxel, channel) copies the <= T points in order, zero-fills the rest,
+//               counts them and (fused MeanVFE) divides the running sum by max(count, 1).
+// All table traffic inside a launch is atomic (no plain re-read of a word another CU's atomic wrote);
+// kernels hand data to each other only across launch boundaries.
+#include "pvx_common.h"
+
+namespace {
+
+constexpr int kBlk = 256;
+constexpr int kScanBlk = 1024;
+constexpr unsigned long long kEmptyKey = ~0ull;
+constexpr int kSentinel = 0x7f7f7f7f;   // what hipMemsetAsync(0x7f) leaves; larger than any point index
+
+struct VoxGeom {
+    float x0, y0, z0, vx, vy, vz;
+    int gx, gy, gz;
+};
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// floor((p - min) / vsize) in binary32 (IEEE division), accepted only inside [0, grid)
+__device__ __forceinline__ bool cell_of(float p, float lo, float vs, int g, int& c) {
+    const float f = floorf((p - lo) / vs);
+    if (!(f >= 0.f && f < (float)g)) return false;
+    c = (int)f;
+    return true;
+}
+
+__global__ __launch_bounds__(kBlk) void vox_insert_kernel(const float* __restrict__ pts, int n, int c, VoxGeom g,
+                                                           unsigned long long* keys, int* first, unsigned cap_mask,
+                                                           int* __restrict__ slot_of_point) {
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + (size_t)i * c;
+    int cx, cy, cz;
+    if (!(cell_of(p[0], g.x0, g.vx, g.gx, cx) && cell_of(p[1], g.y0, g.vy, g.gy, cy) && cell_of(p[2], g.z0, g.vz, g.gz, cz))) {
+        slot_of_point[i] = -1;
+        return;
+    }
+    const unsigned long long key = ((unsigned long long)cz * (unsigned long long)g.gy + (unsigned long long)cy) *
+                                   (unsigned long long)g.gx + (unsigned long long)cx;
+    unsigned h = (unsigned)mix64(key) & cap_mask;
+    int slot = -1;
+    for (unsigned probe = 0; probe <= cap_mask; probe++) {   // bounded: every wave leaves this loop
+        const unsigned long long old = atomicCAS(&keys[h], kEmptyKey, key);
+        if (old == kEmptyKey || old == key) { slot = (int)h; break; }
+        h = (h + 1) & cap_mask;
+    }
+    if (slot >= 0) atomicMin(&first[slot], i);
+    slot_of_point[i] = slot;
+}
+
+// rank of this thread's flag among the block's flags (exclusive) + block total, via ballot / popcount
+__device__ __forceinline__ int block_rank(bool flag, int* wave_sums, int& block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_sums[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, total = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; w++) {
+        const int s = wave_sums[w];
+        if (w < wave) before += s;
+        total += s;
+    }
+    block_total = total;
+    return before + in_wave;
+}
+
+__global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __restrict__ slot_of_point,
+                                                                    const int* __restrict__ first, int n,
+                                                                    int* __restrict__ block_sums) {
+    __shared__ int wave_sums[kScanBlk / 64];
+    const int i = blockIdx.x * kScanBlk + threadIdx.x;
+    bool flag = false;
+    if (i < n) { const int s = slot_of_point[i]; flag = s >= 0 && first[s] == i; }
+    int total;
+    block_rank(flag, wave_sums, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// exclusive scan of nb block sums in place (one workgroup, chunks of 1024), total -> out_counts
+__global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(int* __restrict__ block_sums, int nb, int max_voxels,
+                                                                    int* __restrict__ num_voxels) {
+    __shared__ int buf[kScanBlk];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += kScanBlk) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? block_sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlk; off <<= 1) {   // Hillis-Steele inclusive scan in LDS
+            const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int carry = carry_s;
+        if (i < nb) block_sums[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlk - 1) carry_s = carry + buf[kScanBlk - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int total = carry_s;
+        num_voxels[0] = total < max_voxels ? total : max_voxels;
+    }
+}
+
+__global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restrict__ slot_of_point,
+                                                               const int* __restrict__ first,
+                                                               const unsigned long long* __restrict__ keys, int n,
+                                                               const int* __restrict__ block_offsets, VoxGeom g,
+                                                               int max_voxels, int* __restrict__ vid_of_slot,
+                                                               int* __restrict__ coords_zyx) {
+    __shared__ int wave_sums[kScanBlk / 64];
+    const int i = blockIdx.x * kScanBlk + threadIdx.x;
+    bool flag = false;
+    int s = -1;
+    if (i < n) { s = slot_of_point[i]; flag = s >= 0 && first[s] == i; }
+    int total;
+    const int rank = block_offsets[blockIdx.x] + block_rank(flag, wave_sums, total);
+    if (flag) {
+        vid_of_slot[s] = rank;
+        if (rank < max_voxels) {
+            unsigned long long key = keys[s];
+            const int cx = (int)(key % (unsigned long long)g.gx); key /= (unsigned long long)g.gx;
+            const int cy = (int)(key % (unsigned long long)g.gy);
+            const int cz = (int)(key / (unsigned long long)g.gy);
+            coords_zyx[rank * 3 + 0] = cz; coords_zyx[rank * 3 + 1] = cy; coords_zyx[rank * 3 + 2] = cx;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict__ slot_of_point,
+                                                           const int* __restrict__ vid_of_slot, int n, int T,
+                                                           int max_voxels, int* lists, int* __restrict__ point_to_voxel) {
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n) return;
+    const int s = slot_of_point[i];
+    int vid = -1;
+    if (s >= 0) { vid = vid_of_slot[s]; if (vid >= max_voxels) vid = -1; }
+    if (point_to_voxel) point_to_voxel[i] = vid;
+    if (vid < 0) return;
+    int* L = lists + (size_t)vid * T;
+    // already T smaller indices present?  (values only ever decrease, so a stale read only costs work)
+    if (__hip_atomic_load(&L[T - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) return;
+    int v = i;
+    for (int t = 0; t < T; t++) {
+        const int old = atomicMin(&L[t], v);
+        if (old == kSentinel) break;   // landed in an empty slot
+        if (old > v) v = old;          // displaced a larger index: carry it on
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restrict__ pts, int n, int c, int T,
+                                                           const int* __restrict__ lists,
+                                                           const int* __restrict__ num_voxels,
+                                                           float* __restrict__ voxels, int* __restrict__ num_per_voxel,
+                                                           float* __restrict__ mean) {
+    const long long idx = (long long)blockIdx.x * kBlk + threadIdx.x;
+    const int nv = num_voxels[0];
+    if (idx >= (long long)nv * c) return;
+    const int v = (int)(idx / c), ch = (int)(idx % c);
+    const int* L = lists + (size_t)v * T;
+    float sum = 0.f;
+    int cnt = 0;
+    for (int t = 0; t < T; t++) {
+        const int pi = L[t];
+        float val = 0.f;
+        if (pi < n) { val = pts[(size_t)pi * c + ch]; cnt++; }
+        if (voxels) voxels[((size_t)v * T + t) * c + ch] = val;
+        sum += val;
+    }
+    if (ch == 0 && num_per_voxel) num_per_voxel[v] = cnt;
+    if (mean) mean[(size_t)v * c + ch] = sum / (float)(cnt < 1 ? 1 : cnt);
+}
+
+__global__ __launch_bounds__(kBlk) void mean_vfe_kernel(const float* __restrict__ voxels, const int* __restrict__ num,
+                                                         long long total, int T, int c, float* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * kBlk + threadIdx.x;
+    if (idx >= total) return;
+    const long long v = idx / c;
+    const int ch = (int)(idx % c);
+    float s = 0.f;
+    for (int t = 0; t < T; t++) s += voxels[((size_t)v * T + t) * c + ch];
+    const int k = num[v];
+    out[idx] = s / (float)(k < 1 ? 1 : k);
+}
+
+size_t table_capacity(int n) {
+    size_t cap = 1024;
+    while (cap < (size_t)n * 2 + 2) cap <<= 1;
+    return cap;
+}
+
+struct VoxWorkspace {
+    unsigned long long* keys; int* first; int* vid_of_slot; int* slot_of_point; int* block_sums; int* lists;
+};
+
+template <typename C>
+void carve(C& c, int n, int max_voxels, int T, VoxWorkspace* w) {
+    const size_t cap = table_capacity(n);
+    auto k = c.template take<unsigned long long>(cap);
+    auto f = c.template take<int>(cap);
+    auto vs = c.template take<int>(cap);
+    auto sp = c.template take<int>((size_t)(n > 0 ? n : 1));
+    auto bs = c.template take<int>((size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
+    auto li = c.template take<int>((size_t)max_voxels * T);
+    if (w) { w->keys = (unsigned long long*)k; w->first = (int*)f; w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp;
+             w->block_sums = (int*)bs; w->lists = (int*)li; }
+}
+
+struct SizerShim {   // gives PvxSizer the pointer-returning interface carve() expects
+    PvxSizer s;
+    template <typename T> T* take(size_t count) { s.take<T>(count); return nullptr; }
+};
+
+}  // namespace
+
+extern "C" int pvx_voxel_grid_size(const float* vsize_xyz, const float* range_xyz, int* grid_xyz) {
+    if (!vsize_xyz || !range_xyz || !grid_xyz) return PVX_ERR_INVALID;
+    for (int j = 0; j < 3; j++) {
+        if (!(vsize_xyz[j] > 0.f)) return PVX_ERR_INVALID;
+        grid_xyz[j] = (int)roundf((range_xyz[3 + j] - range_xyz[j]) / vsize_xyz[j]);
+        if (grid_xyz[j] <= 0) return PVX_ERR_INVALID;
+    }
+    return PVX_OK;
+}
+
+extern "C" size_t pvx_voxelize_hard_workspace_bytes(int n_points, int max_voxels, int max_points_per_voxel) {
+    if (n_points < 0 || max_voxels <= 0 || max_points_per_voxel <= 0) return 256;
+    SizerShim s;
+    carve(s, n_points, max_voxels, max_points_per_voxel, nullptr);
+    return s.s.total();
+}
+
+extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                                 int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
+                                 int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    const int T = max_points_per_voxel;
+    if (n < 0 || c < 3 || T <= 0 || max_voxels <= 0 || !coords_zyx || !num_voxels || (n > 0 && !points)) return PVX_ERR_INVALID;
+    if ((long long)max_voxels * T > 0x7fffffffll) return PVX_ERR_RANGE;
+    int grid[3];
+    int rc = pvx_voxel_grid_size(vsize_xyz, range_xyz, grid);
+    if (rc != PVX_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { PVX_CHECK_HIP(hipMemsetAsync(num_voxels, 0, sizeof(int), st)); return PVX_OK; }
+    VoxGeom g = { range_xyz[0], range_xyz[1], range_xyz[2], vsize_xyz[0], vsize_xyz[1], vsize_xyz[2], grid[0], grid[1], grid[2] };
+    PvxCarver cv(workspace, workspace_bytes);
+    VoxWorkspace w;
+    carve(cv, n, max_voxels, T, &w);
+    if (!cv.ok()) return PVX_ERR_WORKSPACE;
+    const size_t cap = table_capacity(n);
+    PVX_CHECK_HIP(hipMemsetAsync(w.keys, 0xff, cap * sizeof(unsigned long long), st));
+    PVX_CHECK_HIP(hipMemsetAsync(w.first, 0x7f, cap * sizeof(int), st));
+    PVX_CHECK_HIP(hipMemsetAsync(w.lists, 0x7f, (size_t)max_voxels * T * sizeof(int), st));
+    const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts), dim3(kBlk), 0, st, points, n, c, g, w.keys, w.first,
+                       (unsigned)(cap - 1), w.slot_of_point);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, n, w.block_sums);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, max_voxels, num_voxels);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, w.keys, n,
+                       w.block_sums, g, max_voxels, w.vid_of_slot, coords_zyx);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, T, max_voxels,
+                       w.lists, point_to_voxel);
+    PVX_CHECK_LAUNCH();
+    const long long work = (long long)max_voxels * c;
+    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk)), dim3(kBlk), 0, st, points, n, c, T,
+                       w.lists, num_voxels, voxels, num_points_per_voxel, mean);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,
+                            float* out, void* stream) {
+    if (m < 0 || max_points_per_voxel <= 0 || c <= 0) return PVX_ERR_INVALID;
+    if (m == 0) return PVX_OK;
+    if (!voxels || !num_points_per_voxel || !out) return PVX_ERR_INVALID;
+    const long long total = (long long)m * c;
+    hipLaunchKernelGGL(mean_vfe_kernel, dim3((unsigned)PVX_CDIV(total, (long long)kBlk)), dim3(kBlk), 0, (hipStream_t)stream,
+                       voxels, num_points_per_voxel, total, max_points_per_voxel, c, out);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
