@@ -81,6 +81,38 @@ int pvx_nms_batched(const float* boxes, const int* counts, int segments, int n_c
 int pvx_boxes_iou_bev_cpu(const float* a, int n, const float* b, int m, float* out);
 int pvx_boxes_aligned_iou_bev_cpu(const float* a, const float* b, int n, float* out);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Voxelization + mean VFE
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* HOST: grid_xyz[j] = round((range[3+j] - range[j]) / vsize[j]) in binary32 -- the grid Point2VoxelCPU3d derives
+ * from (vsize_xyz, coors_range_xyz) [spconv]; pcdet computes the same in DataProcessor.__init__
+ * (pcdet/datasets/processor/data_processor.py:66-78 -> calculate_grid_size). */
+int pvx_voxel_grid_size(const float* vsize_xyz, const float* range_xyz, int* grid_xyz);
+
+/* HOST: workspace bytes for pvx_voxelize_hard. */
+size_t pvx_voxelize_hard_workspace_bytes(int n_points, int max_voxels, int max_points_per_voxel);
+
+/* Hard, first-come voxelization of ONE frame on the device, with MeanVFE fused in.
+ * Replaces VoxelGeneratorWrapper.generate -> spconv.utils.Point2VoxelCPU3d.point_to_voxel [spconv]
+ * (pcdet/datasets/processor/data_processor.py:45-61, call site :200-247) and MeanVFE.forward
+ * (pcdet/models/backbones_3d/vfe/mean_vfe.py:14-33).
+ *   points [n, c] f32, xyz in the first three columns (c >= 3); vsize_xyz[3], range_xyz[6] are HOST arrays.
+ *   voxels [max_voxels, T, c] f32 or NULL; coords_zyx [max_voxels, 3] i32; num_points_per_voxel [max_voxels] i32 or NULL;
+ *   mean [max_voxels, c] f32 or NULL (= voxels.sum(1) / max(num, 1)); point_to_voxel [n] i32 or NULL (-1 = dropped);
+ *   num_voxels: device i32, = M.  Only rows < M of the outputs are written.
+ * Voxel ids follow first appearance in input order, a voxel keeps its first T points in input order, cells first
+ * seen after max_voxels ids were handed out are dropped: identical to the sequential CPU algorithm, bit-exact. */
+int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                      int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
+                      int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[m, c] = voxels[m, T, c].sum(1) / max(num[m], 1).  MeanVFE.forward (mean_vfe.py:26-31) for callers that
+ * already hold the padded voxel tensor. */
+int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,
+                 float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,36 @@ def ref_boxes_aligned_iou_bev(a, b):
     out = np.zeros((a.shape[0], 1), np.float32)
     ref().ref_boxes_aligned_iou_bev_cpu(fptr(a), fptr(b), a.shape[0], fptr(out))
     return out[:, 0]
+
+
+# ---------------------------------------------------------------------------------------------------
+# voxelization
+# ---------------------------------------------------------------------------------------------------
+def voxel_grid_size(vsize_xyz, range_xyz):
+    v, r = f32(vsize_xyz), f32(range_xyz)
+    g = np.zeros(3, np.int32)
+    oracle().orc_voxel_grid_size(fptr(v), fptr(r), g.ctypes.data_as(_ip))
+    return g.tolist()
+
+
+def voxelize_hard(points, vsize_xyz, range_xyz, T, max_voxels):
+    """-> voxels [M,T,C], coords_zyx [M,3], num_per_voxel [M], point_to_voxel [N]"""
+    p = f32(points)
+    n, c = p.shape
+    v, r = f32(vsize_xyz), f32(range_xyz)
+    voxels = np.zeros((max_voxels, T, c), np.float32)
+    coords = np.zeros((max_voxels, 3), np.int32)
+    num = np.zeros((max_voxels,), np.int32)
+    p2v = np.zeros((max(n, 1),), np.int32)
+    m = oracle().orc_voxelize_hard(fptr(p), n, c, fptr(v), fptr(r), int(T), int(max_voxels), fptr(voxels),
+                                   coords.ctypes.data_as(_ip), num.ctypes.data_as(_ip), p2v.ctypes.data_as(_ip))
+    return voxels[:m].copy(), coords[:m].copy(), num[:m].copy(), p2v[:n].copy()
+
+
+def mean_vfe(voxels, num):
+    vx = f32(voxels)
+    m, T, c = vx.shape
+    nm = np.ascontiguousarray(num, np.int32)
+    out = np.zeros((m, c), np.float32)
+    oracle().orc_mean_vfe(fptr(vx), nm.ctypes.data_as(_ip), m, T, c, fptr(out))
+    return out

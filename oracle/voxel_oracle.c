@@ -54,9 +54,9 @@ int orc_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz,
         int cc[3];
         int ok = 1;
         for (int j = 0; j < 3; j++) {
-            int v = (int)floorf((points[(size_t)i * c + j] - range_xyz[j]) / vsize_xyz[j]);
-            if (v < 0 || v >= grid[j]) { ok = 0; break; }
-            cc[j] = v;
+            float f = floorf((points[(size_t)i * c + j] - range_xyz[j]) / vsize_xyz[j]);
+            if (!(f >= 0.f && f < (float)grid[j])) { ok = 0; break; }   /* also rejects NaN / out-of-int-range */
+            cc[j] = (int)f;
         }
         if (point_to_voxel) point_to_voxel[i] = -1;
         if (!ok) continue;
