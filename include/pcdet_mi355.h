@@ -113,6 +113,89 @@ int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz,
 int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,
                  float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Sparse convolution: site index, rulebook (indice pairs), implicit-GEMM forward, dense()
+ *
+ * Replaces what the reference gets from the third-party spconv package [spconv] behind
+ * SparseConvTensor / SubMConv3d / SparseConv3d / SparseInverseConv3d
+ * (pcdet/utils/spconv_utils.py:3-10; call sites pcdet/models/backbones_3d/spconv_backbone.py:8-27,30-67,
+ *  79-120,196-237; pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:81-138).
+ *
+ * Conventions: indices rows are (b, z, y, x) int32, 4 per row; shape_dhw = {D, H, W}; kernel offset
+ * k = (kz*KH + ky)*KW + kx; weight is the reference's [Cout, kz, ky, kx, Cin] (libraries/3DSparseConvolution/
+ * tool/centerpoint-export/funcs.py:46-63, pcdet/models/detectors/detector3d_template.py:357-368);
+ * the rulebook is the neighbour table nbr[K][n_out]: input row feeding output row o through offset k, or -1.
+ *
+ * Row counts that depend on the data live on the DEVICE: wherever a function takes (n, n_dev), `n` is the row
+ * capacity (grid size and row stride of nbr) and `n_dev` -- optional, NULL = use n -- points at the live count
+ * an earlier call on the same stream produced.  Nothing here synchronises with the host.
+ * 2-D convolutions (SubMConv2d / SparseConv2d) are the D = 1, kz = 1 case.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* HOST: bytes of one site index (occupancy bitmap + rank prefix, 16 B per 64 cells) over batch x D x H x W;
+ * 0 if the grid is invalid or beyond 2^34 cells. */
+size_t pvx_site_index_bytes(int batch, const int* shape_dhw);
+/* HOST: workspace bytes for pvx_site_index_build / pvx_conv_out_index on that grid. */
+size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw);
+
+/* Build the site index of a coordinate set: afterwards rank(cell) = position of the cell in ascending linear key
+ * ((b*D + z)*H + y)*W + x among the active cells.  perm (optional, [n]) receives perm[rank] = input row, i.e. the
+ * map from key order to the caller's row order (hard voxels arrive in first-come order).  *n_unique (device)
+ * = number of distinct active cells.  Rows with out-of-grid coordinates are ignored.
+ * Replaces spconv's hash-table build inside get_indice_pairs [spconv]. */
+int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
+                         int* perm, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Submanifold rulebook: nbr[k][o] = row of the site at coords[o] + (k - K/2) * dilation, or -1.  Output rows
+ * are the input rows (SubMConv3d, spconv_backbone.py:12,39-46).  ksize odd per axis. */
+int pvx_subm_rulebook(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                      const int* perm, const int* ksize, const int* dilation, int* nbr, void* stream);
+
+/* HOST: out = floor((in + 2p - d(k-1) - 1)/s) + 1 per axis (spconv.ops.get_conv_output_size [spconv], used by
+ * libraries/3DSparseConvolution/tool/centerpoint-export/exptool.py:76-82). */
+int pvx_conv_out_shape(const int* in_shape, const int* ksize, const int* stride, const int* padding,
+                       const int* dilation, int* out_shape);
+
+/* Strided sparse conv (SparseConv3d, spconv_backbone.py:14-15), step 1: mark every output cell reached by at least
+ * one (input site, kernel offset) and build the OUTPUT grid's site index; *n_out (device) = number of output sites.
+ * out_index has pvx_site_index_bytes(batch, out_shape) bytes and doubles as the site index of the output tensor. */
+int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
+                       const int* ksize, const int* stride, const int* padding, const int* dilation, void* out_index,
+                       int* n_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Step 2: coords_out [n_out, 4] in ascending key order (the row-order contract) and nbr [K][n_out] against the
+ * input tensor's site index (in_perm as in pvx_site_index_build, NULL when input rows are already in key order). */
+int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
+                          const int* ksize, const int* stride, const int* padding, const int* dilation,
+                          const void* in_index, const int* in_perm, int* coords_out, int* nbr, void* stream);
+
+/* Transposed use of a forward table (SparseInverseConv3d, spconv_backbone.py:17): nbr_inv[k][i] = o  <=>
+ * nbr_fwd[k][o] = i.  nbr_fwd is [K][n_out_fwd], nbr_inv is [K][n_in_fwd]. */
+int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd, int n_in_fwd, int* nbr_inv, void* stream);
+
+/* HOST: 1 when (cin, cout, dtype) runs on the MFMA implicit-GEMM kernel, 0 when on the generic fp32-math kernel. */
+int pvx_sparse_conv_uses_mfma(int cin, int cout, int dtype);
+/* HOST: bytes of the kernel-ready copy of a [cout, kvol, cin] weight. */
+size_t pvx_sparse_conv_weight_bytes(int cout, int kvol, int cin, int dtype);
+/* Re-lay a [cout, kvol, cin] weight (the module's parameter, dtype PVX_*) into the kernel's fragment order.
+ * Done once per layer per weight update, not per forward. */
+int pvx_sparse_conv_prepare_weight(const void* weight, int cout, int kvol, int cin, int dtype, void* prepared,
+                                   void* stream);
+
+/* out[o, :] = act( (bias + sum_k W[:, k, :] . feat_in[nbr[k][o], :]) * scale + shift + residual[o, :] )
+ * for o < live rows.  feat_in [n_in, cin], out / residual [n_out, cout], all of `dtype`; bias / scale / shift are
+ * f32 [cout] or NULL (scale and shift together: an eval-mode BatchNorm1d folded in, as the reference's own export
+ * path folds it, centerpoint-export/funcs.py:46-63); relu != 0 applies max(., 0).  Accumulation is fp32.
+ * Replaces SparseConvolution.forward's indice_conv / implicit_gemm [spconv]; one write per output row, no atomics. */
+int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                        const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
+                        const float* scale, const float* shift, const void* residual, int relu, void* out, void* stream);
+
+/* SparseConvTensor.dense() (pcdet/models/backbones_2d/map_to_bev/height_compression.py:22): zero-fill
+ * out [batch, c, D, H, W] and scatter the rows, writing the channel-major layout directly. */
+int pvx_sparse_to_dense(const void* feat, const int* coords, int n, const int* n_dev, int c, int dtype, int batch,
+                        const int* shape_dhw, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,35 @@ SIGNATURES = {
     "pvx_voxelize_hard": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
+    "pvx_site_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
+    "pvx_site_index_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    "pvx_subm_rulebook": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "pvx_conv_out_shape": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pvx_conv_out_index": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_conv_out_rulebook": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pvx_inverse_rulebook": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pvx_sparse_conv_uses_mfma": (c_int, [c_int, c_int, c_int]),
+    "pvx_sparse_conv_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "pvx_sparse_conv_prepare_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pvx_sparse_conv_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                    c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pvx_sparse_to_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p]),
 }
+
+
+def int3(v):
+    """host int[3] from an int or a 3-sequence (kernel_size / stride / padding / dilation / shape arguments)."""
+    if isinstance(v, int):
+        v = (v, v, v)
+    v = [int(x) for x in v]
+    assert len(v) == 3
+    return (ctypes.c_int * 3)(*v)
 
 
 def lib():

@@ -1,0 +1,384 @@
+// Site index + rulebook (indice-pair) generation for spconv-style sparse convolutions on gfx950.
+//
+// Replaces the indice-pair generation the reference gets from the external spconv package
+// (spconv.ops.get_indice_pairs[_implicit_gemm] behind SubMConv3d / SparseConv3d / SparseInverseConv3d as used in
+// pcdet/models/backbones_3d/spconv_backbone.py:8-27,79-120,196-237; semantics SURVEY.md 8a-6..8a-8, oracle/spconv_oracle.c).
+//
+// Data structure (DESIGN.md "Site index"): instead of a hash table, every site set is indexed by an occupancy
+// BITMAP over the (batch x D x H x W) grid plus a popcount prefix per 64-cell word, stored as 16-byte entries
+// {bits, prefix}: one 16-B load answers "is cell q active, and what is its rank in ascending key order".
+//  * 27 neighbours of a site touch ~9 words (x-neighbours share a word), not 27 random hash slots;
+//  * rank order == ascending linear key == the row order contract for strided-conv outputs, so output
+//    coordinates come out sorted with no sort;
+//  * the output bitmap of a strided conv is reused as the site index of its output tensor (the next
+//    submanifold layers), so each resolution level builds exactly one index per forward.
+// The rulebook is the neighbour table nbr[K][N_out] (input row or -1), written coalesced along N_out; it is what
+// the implicit-GEMM kernels in sparse_conv.hip consume.
+#include "pvx_common.h"
+#include "scan_util.h"
+
+namespace {
+
+constexpr int kBlk = 256;
+
+struct alignas(16) IndexEntry {
+    unsigned long long bits;
+    unsigned prefix;
+    unsigned pad;
+};
+
+struct Dims { int b, d, h, w; };
+
+struct ConvGeom {
+    Dims in, out;
+    int k[3], s[3], p[3], dil[3];
+};
+
+__device__ __forceinline__ long long lin_key(int b, int z, int y, int x, const Dims& s) {
+    return (((long long)b * s.d + z) * s.h + y) * s.w + x;
+}
+
+__device__ __forceinline__ int rank_of(const IndexEntry* __restrict__ idx, long long key) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(idx + (key >> 6));
+    const unsigned long long bits = ((unsigned long long)raw.y << 32) | raw.x;
+    const int bit = (int)(key & 63);
+    if (!((bits >> bit) & 1ull)) return -1;
+    return (int)raw.z + __popcll(bits & ((1ull << bit) - 1ull));
+}
+
+// every kernel takes (n, n_dev): n is the row capacity the grid is sized for, *n_dev (when given) the live row
+// count produced by an earlier kernel on the same stream -- no host round trip for data-dependent sizes
+__device__ __forceinline__ int live_rows(int n, const int* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const int v = *n_dev;
+    return v < n ? v : n;
+}
+
+__global__ __launch_bounds__(kBlk) void idx_setbits_kernel(const int* __restrict__ coords, int n_cap,
+                                                            const int* __restrict__ n_dev, Dims s, IndexEntry* idx) {
+    const int n = live_rows(n_cap, n_dev);
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (c.x < 0 || c.x >= s.b || c.y < 0 || c.y >= s.d || c.z < 0 || c.z >= s.h || c.w < 0 || c.w >= s.w) return;
+    const long long key = lin_key(c.x, c.y, c.z, c.w, s);
+    atomicOr(&idx[key >> 6].bits, 1ull << (key & 63));
+}
+
+__global__ __launch_bounds__(pvx::kScanBlock) void idx_count_kernel(const IndexEntry* __restrict__ idx, long long words,
+                                                                     int* __restrict__ block_sums) {
+    __shared__ int wave_sums[pvx::kScanBlock / 64];
+    const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
+    const int v = w < words ? __popcll(idx[w].bits) : 0;
+    int total;
+    pvx::block_exclusive_scan(v, wave_sums, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(pvx::kScanBlock) void idx_prefix_kernel(IndexEntry* __restrict__ idx, long long words,
+                                                                      const int* __restrict__ block_offsets) {
+    __shared__ int wave_sums[pvx::kScanBlock / 64];
+    const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
+    const int v = w < words ? __popcll(idx[w].bits) : 0;
+    int total;
+    const int ex = pvx::block_exclusive_scan(v, wave_sums, total);
+    if (w < words) idx[w].prefix = (unsigned)(block_offsets[blockIdx.x] + ex);
+}
+
+__global__ __launch_bounds__(kBlk) void idx_perm_kernel(const int* __restrict__ coords, int n_cap,
+                                                         const int* __restrict__ n_dev, Dims s,
+                                                         const IndexEntry* __restrict__ idx, int* __restrict__ perm) {
+    const int n = live_rows(n_cap, n_dev);
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (c.x < 0 || c.x >= s.b || c.y < 0 || c.y >= s.d || c.z < 0 || c.z >= s.h || c.w < 0 || c.w >= s.w) return;
+    const int r = rank_of(idx, lin_key(c.x, c.y, c.z, c.w, s));
+    if (r >= 0) perm[r] = i;   // duplicate coordinates: one of the rows wins (callers pass unique coordinates)
+}
+
+// Submanifold table: thread = output site, loop over the K offsets; nbr[k][o] stores are coalesced along o.
+__global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restrict__ coords, int n,
+                                                              const int* __restrict__ n_dev, Dims s,
+                                                              const IndexEntry* __restrict__ idx,
+                                                              const int* __restrict__ perm, int kd, int kh, int kw,
+                                                              int dd, int dh, int dw, int* __restrict__ nbr) {
+    const int o = blockIdx.x * kBlk + threadIdx.x;
+    if (o >= live_rows(n, n_dev)) return;   // nbr keeps the CAPACITY n as its row stride
+    const int4 c = reinterpret_cast<const int4*>(coords)[o];
+    int k = 0;
+    for (int a = 0; a < kd; a++) {
+        const int z = c.y + (a - kd / 2) * dd;
+        for (int bq = 0; bq < kh; bq++) {
+            const int y = c.z + (bq - kh / 2) * dh;
+            for (int cq = 0; cq < kw; cq++, k++) {
+                const int x = c.w + (cq - kw / 2) * dw;
+                int v = -1;
+                if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w && c.x >= 0 && c.x < s.b) {
+                    const int r = rank_of(idx, lin_key(c.x, z, y, x, s));
+                    if (r >= 0) v = perm ? perm[r] : r;
+                }
+                nbr[(size_t)k * n + o] = v;
+            }
+        }
+    }
+}
+
+// Strided conv, phase 1: mark every output cell reached by some (input site, offset).
+__global__ __launch_bounds__(kBlk) void conv_out_setbits_kernel(const int* __restrict__ coords, int n_in_cap,
+                                                                 const int* __restrict__ n_in_dev, ConvGeom g,
+                                                                 IndexEntry* out_idx) {
+    const int n_in = live_rows(n_in_cap, n_in_dev);
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n_in) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (c.x < 0 || c.x >= g.in.b) return;
+    for (int a = 0; a < g.k[0]; a++) {
+        const int tz = c.y + g.p[0] - a * g.dil[0];
+        if (tz < 0 || tz % g.s[0] != 0) continue;
+        const int oz = tz / g.s[0];
+        if (oz >= g.out.d) continue;
+        for (int bq = 0; bq < g.k[1]; bq++) {
+            const int ty = c.z + g.p[1] - bq * g.dil[1];
+            if (ty < 0 || ty % g.s[1] != 0) continue;
+            const int oy = ty / g.s[1];
+            if (oy >= g.out.h) continue;
+            for (int cq = 0; cq < g.k[2]; cq++) {
+                const int tx = c.w + g.p[2] - cq * g.dil[2];
+                if (tx < 0 || tx % g.s[2] != 0) continue;
+                const int ox = tx / g.s[2];
+                if (ox >= g.out.w) continue;
+                const long long key = lin_key(c.x, oz, oy, ox, g.out);
+                atomicOr(&out_idx[key >> 6].bits, 1ull << (key & 63));
+            }
+        }
+    }
+}
+
+// phase 2a: enumerate the set bits of every word in order -> coords_out rows in ascending key order
+__global__ __launch_bounds__(kBlk) void conv_out_coords_kernel(const IndexEntry* __restrict__ idx, long long words,
+                                                                Dims s, int n_out, int* __restrict__ coords_out) {
+    // n_out is the CAPACITY of coords_out here: ranks beyond it are dropped (the caller sized it too small)
+    const long long w = (long long)blockIdx.x * kBlk + threadIdx.x;
+    if (w >= words) return;
+    unsigned long long bits = idx[w].bits;
+    int r = (int)idx[w].prefix;
+    while (bits) {
+        const int bit = __ffsll((long long)bits) - 1;
+        bits &= bits - 1ull;
+        long long key = (w << 6) + bit;
+        const int x = (int)(key % s.w); key /= s.w;
+        const int y = (int)(key % s.h); key /= s.h;
+        const int z = (int)(key % s.d);
+        const int b = (int)(key / s.d);
+        if (r < n_out) reinterpret_cast<int4*>(coords_out)[r] = make_int4(b, z, y, x);
+        r++;
+    }
+}
+
+// phase 2b: thread = output site, loop over offsets, look the input cell up in the INPUT index
+__global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __restrict__ coords_out, int n_out,
+                                                                  const int* __restrict__ n_out_dev, ConvGeom g,
+                                                                  const IndexEntry* __restrict__ in_idx,
+                                                                  const int* __restrict__ in_perm,
+                                                                  int* __restrict__ nbr) {
+    const int o = blockIdx.x * kBlk + threadIdx.x;
+    if (o >= live_rows(n_out, n_out_dev)) return;
+    const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
+    int k = 0;
+    for (int a = 0; a < g.k[0]; a++) {
+        const int z = c.y * g.s[0] - g.p[0] + a * g.dil[0];
+        for (int bq = 0; bq < g.k[1]; bq++) {
+            const int y = c.z * g.s[1] - g.p[1] + bq * g.dil[1];
+            for (int cq = 0; cq < g.k[2]; cq++, k++) {
+                const int x = c.w * g.s[2] - g.p[2] + cq * g.dil[2];
+                int v = -1;
+                if (z >= 0 && z < g.in.d && y >= 0 && y < g.in.h && x >= 0 && x < g.in.w) {
+                    const int r = rank_of(in_idx, lin_key(c.x, z, y, x, g.in));
+                    if (r >= 0) v = in_perm ? in_perm[r] : r;
+                }
+                nbr[(size_t)k * n_out + o] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void inverse_rulebook_kernel(const int* __restrict__ nbr_fwd, long long total,
+                                                                 int n_out_fwd, int n_in_fwd, int* __restrict__ nbr_inv) {
+    const long long t = (long long)blockIdx.x * kBlk + threadIdx.x;
+    if (t >= total) return;
+    const int i = nbr_fwd[t];
+    if (i >= 0 && i < n_in_fwd) {
+        const long long k = t / n_out_fwd;
+        nbr_inv[k * n_in_fwd + i] = (int)(t - k * n_out_fwd);
+    }
+}
+
+bool dims_ok(const Dims& s, long long* words) {
+    if (s.b <= 0 || s.d <= 0 || s.h <= 0 || s.w <= 0) return false;
+    const long long cells = (long long)s.b * s.d * s.h * s.w;
+    if (cells <= 0 || cells / s.w / s.h / s.d != s.b) return false;
+    *words = (cells + 63) / 64;
+    return true;
+}
+
+constexpr long long kMaxWords = 1ll << 28;   // 16 Gi cells, 4 GiB of index: beyond this use a coarser partition
+
+int scan_index(IndexEntry* idx, long long words, int* block_sums, int* total_dev, hipStream_t st) {
+    const int nb = (int)PVX_CDIV(words, (long long)pvx::kScanBlock);
+    hipLaunchKernelGGL(idx_count_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pvx::scan_block_sums_kernel, dim3(1), dim3(pvx::kScanBlock), 0, st, block_sums, nb, -1, total_dev);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(idx_prefix_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+int read_geom(const int* in_shape, int batch, const int* ksize, const int* stride, const int* padding, const int* dilation,
+              ConvGeom* g) {
+    if (!in_shape || !ksize || !stride || !padding || !dilation) return PVX_ERR_INVALID;
+    g->in = { batch, in_shape[0], in_shape[1], in_shape[2] };
+    int o[3];
+    for (int j = 0; j < 3; j++) {
+        if (ksize[j] <= 0 || stride[j] <= 0 || dilation[j] <= 0 || padding[j] < 0) return PVX_ERR_INVALID;
+        g->k[j] = ksize[j]; g->s[j] = stride[j]; g->p[j] = padding[j]; g->dil[j] = dilation[j];
+        o[j] = (in_shape[j] + 2 * padding[j] - dilation[j] * (ksize[j] - 1) - 1) / stride[j] + 1;
+        if (o[j] <= 0) return PVX_ERR_INVALID;
+    }
+    g->out = { batch, o[0], o[1], o[2] };
+    return PVX_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pvx_site_index_bytes(int batch, const int* shape_dhw) {
+    if (!shape_dhw) return 0;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words) || words > kMaxWords) return 0;
+    return (size_t)words * sizeof(IndexEntry);
+}
+
+extern "C" size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw) {
+    if (!shape_dhw) return 256;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words) || words > kMaxWords) return 256;
+    PvxSizer z;
+    z.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
+    return z.total();
+}
+
+extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                    void* index, int* perm, int* n_unique, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    if (n < 0 || !shape_dhw || !index || !n_unique || (n > 0 && !coords)) return PVX_ERR_INVALID;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    if (words > kMaxWords) return PVX_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    PvxCarver cv(workspace, workspace_bytes);
+    int* block_sums = cv.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
+    if (!cv.ok()) return PVX_ERR_WORKSPACE;
+    IndexEntry* idx = (IndexEntry*)index;
+    PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
+    if (n > 0) {
+        hipLaunchKernelGGL(idx_setbits_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx);
+        PVX_CHECK_LAUNCH();
+    }
+    int rc = scan_index(idx, words, block_sums, n_unique, st);
+    if (rc != PVX_OK) return rc;
+    if (perm && n > 0) {
+        hipLaunchKernelGGL(idx_perm_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx, perm);
+        PVX_CHECK_LAUNCH();
+    }
+    return PVX_OK;
+}
+
+extern "C" int pvx_subm_rulebook(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                 const void* index, const int* perm, const int* ksize, const int* dilation, int* nbr,
+                                 void* stream) {
+    if (n < 0 || !shape_dhw || !ksize || !dilation) return PVX_ERR_INVALID;
+    if (n == 0) return PVX_OK;
+    if (!coords || !index || !nbr) return PVX_ERR_INVALID;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    for (int j = 0; j < 3; j++) if (ksize[j] <= 0 || (ksize[j] & 1) == 0 || dilation[j] <= 0) return PVX_ERR_INVALID;
+    hipLaunchKernelGGL(subm_rulebook_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
+                       (const IndexEntry*)index, perm, ksize[0], ksize[1], ksize[2], dilation[0], dilation[1], dilation[2], nbr);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_conv_out_shape(const int* in_shape, const int* ksize, const int* stride, const int* padding,
+                                  const int* dilation, int* out_shape) {
+    ConvGeom g;
+    if (!out_shape) return PVX_ERR_INVALID;
+    int rc = read_geom(in_shape, 1, ksize, stride, padding, dilation, &g);
+    if (rc != PVX_OK) return rc;
+    out_shape[0] = g.out.d; out_shape[1] = g.out.h; out_shape[2] = g.out.w;
+    return PVX_OK;
+}
+
+extern "C" int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
+                                  const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                  void* out_index, int* n_out, void* workspace, size_t workspace_bytes, void* stream) {
+    ConvGeom g;
+    int rc = read_geom(in_shape, batch, ksize, stride, padding, dilation, &g);
+    if (rc != PVX_OK) return rc;
+    if (n_in < 0 || !out_index || !n_out || (n_in > 0 && !coords_in)) return PVX_ERR_INVALID;
+    long long words, in_words;
+    if (!dims_ok(g.out, &words) || !dims_ok(g.in, &in_words)) return PVX_ERR_INVALID;
+    if (words > kMaxWords) return PVX_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    PvxCarver cv(workspace, workspace_bytes);
+    int* block_sums = cv.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
+    if (!cv.ok()) return PVX_ERR_WORKSPACE;
+    IndexEntry* idx = (IndexEntry*)out_index;
+    PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
+    if (n_in > 0) {
+        hipLaunchKernelGGL(conv_out_setbits_kernel, dim3(PVX_CDIV(n_in, kBlk)), dim3(kBlk), 0, st, coords_in, n_in, n_in_dev, g, idx);
+        PVX_CHECK_LAUNCH();
+    }
+    return scan_index(idx, words, block_sums, n_out, st);
+}
+
+extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
+                                     const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                     const void* in_index, const int* in_perm, int* coords_out, int* nbr, void* stream) {
+    ConvGeom g;
+    int rc = read_geom(in_shape, batch, ksize, stride, padding, dilation, &g);
+    if (rc != PVX_OK) return rc;
+    if (n_out < 0) return PVX_ERR_INVALID;
+    if (n_out == 0) return PVX_OK;
+    if (!out_index || !in_index || !coords_out || !nbr) return PVX_ERR_INVALID;
+    long long words;
+    if (!dims_ok(g.out, &words)) return PVX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_out_coords_kernel, dim3((unsigned)PVX_CDIV(words, (long long)kBlk)), dim3(kBlk), 0, st,
+                       (const IndexEntry*)out_index, words, g.out, n_out, coords_out);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(conv_out_rulebook_kernel, dim3(PVX_CDIV(n_out, kBlk)), dim3(kBlk), 0, st, coords_out, n_out, n_out_dev, g,
+                       (const IndexEntry*)in_index, in_perm, nbr);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd, int n_in_fwd, int* nbr_inv, void* stream) {
+    if (kvol <= 0 || n_out_fwd < 0 || n_in_fwd < 0) return PVX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_in_fwd > 0) {
+        if (!nbr_inv) return PVX_ERR_INVALID;
+        PVX_CHECK_HIP(hipMemsetAsync(nbr_inv, 0xff, (size_t)kvol * n_in_fwd * sizeof(int), st));
+    }
+    const long long total = (long long)kvol * n_out_fwd;
+    if (total == 0 || n_in_fwd == 0) return PVX_OK;
+    if (!nbr_fwd) return PVX_ERR_INVALID;
+    hipLaunchKernelGGL(inverse_rulebook_kernel, dim3((unsigned)PVX_CDIV(total, (long long)kBlk)), dim3(kBlk), 0, st, nbr_fwd,
+                       total, n_out_fwd, n_in_fwd, nbr_inv);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}

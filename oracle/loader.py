@@ -132,3 +132,88 @@ def mean_vfe(voxels, num):
     out = np.zeros((m, c), np.float32)
     oracle().orc_mean_vfe(fptr(vx), nm.ctypes.data_as(_ip), m, T, c, fptr(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# sparse convolution
+# ---------------------------------------------------------------------------------------------------
+def _i3(v):
+    if isinstance(v, int):
+        v = (v, v, v)
+    return (ctypes.c_int * 3)(*[int(x) for x in v])
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def conv_out_shape(in_shape, ksize, stride, padding, dilation=1):
+    out = (ctypes.c_int * 3)()
+    oracle().orc_conv_out_shape(_i3(in_shape), _i3(ksize), _i3(stride), _i3(padding), _i3(dilation), out)
+    return [out[0], out[1], out[2]]
+
+
+def subm_rulebook(coords, shape, ksize, dilation=1):
+    """coords [n,4] (b,z,y,x) -> nbr [K,n] int32"""
+    c = _i32(coords)
+    n = c.shape[0]
+    ks = _i3(ksize)
+    K = ks[0] * ks[1] * ks[2]
+    nbr = np.full((K, max(n, 1)), -1, np.int32)
+    oracle().orc_subm_rulebook(c.ctypes.data_as(_ip), n, _i3(shape), ks, _i3(dilation), nbr.ctypes.data_as(_ip))
+    return nbr[:, :n].copy() if n else np.zeros((K, 0), np.int32)
+
+
+def sparse_rulebook(coords, in_shape, ksize, stride, padding, dilation=1):
+    """strided conv -> (out_coords [n_out,4] ascending key, nbr [K,n_out], out_shape)"""
+    c = _i32(coords)
+    n = c.shape[0]
+    ks = _i3(ksize)
+    K = ks[0] * ks[1] * ks[2]
+    args = (c.ctypes.data_as(_ip), n, _i3(in_shape), ks, _i3(stride), _i3(padding), _i3(dilation))
+    n_out = oracle().orc_sparse_rulebook(*args, None, None)
+    oc = np.zeros((max(n_out, 1), 4), np.int32)
+    nbr = np.full((K, max(n_out, 1)), -1, np.int32)
+    got = oracle().orc_sparse_rulebook(*args, oc.ctypes.data_as(_ip), nbr.ctypes.data_as(_ip))
+    assert got == n_out
+    return oc[:n_out].copy(), np.ascontiguousarray(nbr[:, :n_out]), conv_out_shape(in_shape, ksize, stride, padding, dilation)
+
+
+def inverse_rulebook(nbr_fwd, n_in_fwd):
+    f = _i32(nbr_fwd)
+    K, n_out = f.shape
+    inv = np.full((K, max(n_in_fwd, 1)), -1, np.int32)
+    oracle().orc_inverse_rulebook(f.ctypes.data_as(_ip), K, n_out, n_in_fwd, inv.ctypes.data_as(_ip))
+    return np.ascontiguousarray(inv[:, :n_in_fwd])
+
+
+def sparse_conv_fwd(feat, weight, bias, nbr):
+    """feat [n_in,cin] f32, weight [cout,K,cin] (or [cout,kz,ky,kx,cin]) f32, nbr [K,n_out] -> [n_out,cout] f32"""
+    f = f32(feat)
+    w = f32(weight)
+    cout, cin = w.shape[0], w.shape[-1]
+    w = w.reshape(cout, -1, cin)
+    K = w.shape[1]
+    nb = _i32(nbr)
+    assert nb.shape[0] == K
+    n_out = nb.shape[1]
+    out = np.zeros((max(n_out, 1), cout), np.float32)
+    b = f32(bias) if bias is not None else None
+    oracle().orc_sparse_conv_fwd(fptr(f), cin, fptr(w), fptr(b) if b is not None else None, nb.ctypes.data_as(_ip), K, n_out,
+                                 cout, fptr(out))
+    return out[:n_out].copy()
+
+
+def count_pairs(nbr):
+    nb = _i32(nbr)
+    oracle().orc_count_pairs.restype = ctypes.c_longlong
+    return int(oracle().orc_count_pairs(nb.ctypes.data_as(_ip), nb.shape[0], nb.shape[1]))
+
+
+def dense(feat, coords, batch, shape):
+    f = f32(feat)
+    c = _i32(coords)
+    n, ch = f.shape
+    out = np.zeros((batch, ch, shape[0], shape[1], shape[2]), np.float32)
+    oracle().orc_dense(fptr(f), c.ctypes.data_as(_ip), n, ch, batch, _i3(shape), fptr(out))
+    return out
