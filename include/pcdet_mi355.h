@@ -108,6 +108,20 @@ int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz,
                       int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* Frame `batch_idx` of a batch, voxelized straight into the backbone's input rows with no host round trip: the same
+ * first-come voxelization as pvx_voxelize_hard, but the M voxels are APPENDED at rows [base, base + M) of the
+ * batch-level arrays, base = *row_base_dev (NULL = 0), fusing MeanVFE.forward, the batch-index column that
+ * collate_batch prepends (pcdet/datasets/dataset.py:258-265) and the dtype / channel-padding cast in front of the
+ * first sparse conv:
+ *   coords_bzyx [row_capacity, 4] i32 = (batch_idx, z, y, x);
+ *   mean [row_capacity, mean_stride] of mean_dtype (PVX_*): channels [0, c) = mean of the voxel's first T points,
+ *   channels [c, mean_stride) = 0;  *num_voxels = M;  *row_end_dev = min(base + M, row_capacity) (may alias
+ *   row_base_dev: a running row counter).  Rows beyond row_capacity are dropped. */
+int pvx_voxelize_mean_append(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                             int max_points_per_voxel, int max_voxels, int batch_idx, const int* row_base_dev,
+                             int row_capacity, int* coords_bzyx, void* mean, int mean_stride, int mean_dtype,
+                             int* num_voxels, int* row_end_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[m, c] = voxels[m, T, c].sum(1) / max(num[m], 1).  MeanVFE.forward (mean_vfe.py:26-31) for callers that
  * already hold the padded voxel tensor. */
 int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,

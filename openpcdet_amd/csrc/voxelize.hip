@@ -137,7 +137,9 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
                                                                const unsigned long long* __restrict__ keys, int n,
                                                                const int* __restrict__ block_offsets, VoxGeom g,
                                                                int max_voxels, int* __restrict__ vid_of_slot,
-                                                               int* __restrict__ coords_zyx) {
+                                                               int* __restrict__ coords_zyx, int* __restrict__ coords_bzyx,
+                                                               int batch_idx, const int* __restrict__ row_base_dev,
+                                                               int row_capacity) {
     __shared__ int wave_sums[kScanBlk / 64];
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
@@ -152,7 +154,11 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
             const int cx = (int)(key % (unsigned long long)g.gx); key /= (unsigned long long)g.gx;
             const int cy = (int)(key % (unsigned long long)g.gy);
             const int cz = (int)(key / (unsigned long long)g.gy);
-            coords_zyx[rank * 3 + 0] = cz; coords_zyx[rank * 3 + 1] = cy; coords_zyx[rank * 3 + 2] = cx;
+            if (coords_zyx) { coords_zyx[rank * 3 + 0] = cz; coords_zyx[rank * 3 + 1] = cy; coords_zyx[rank * 3 + 2] = cx; }
+            if (coords_bzyx) {
+                const long long row = (long long)(row_base_dev ? row_base_dev[0] : 0) + rank;
+                if (row < row_capacity) reinterpret_cast<int4*>(coords_bzyx)[row] = make_int4(batch_idx, cz, cy, cx);
+            }
         }
     }
 }
@@ -182,11 +188,21 @@ __global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restric
                                                            const int* __restrict__ lists,
                                                            const int* __restrict__ num_voxels,
                                                            float* __restrict__ voxels, int* __restrict__ num_per_voxel,
-                                                           float* __restrict__ mean) {
+                                                           void* __restrict__ mean, int mean_stride, int mean_dtype,
+                                                           const int* __restrict__ row_base_dev, int row_capacity) {
+    // thread = (voxel, output channel); output channels >= c are the zero padding of a widened mean row
     const long long idx = (long long)blockIdx.x * kBlk + threadIdx.x;
     const int nv = num_voxels[0];
-    if (idx >= (long long)nv * c) return;
-    const int v = (int)(idx / c), ch = (int)(idx % c);
+    if (idx >= (long long)nv * mean_stride) return;
+    const int v = (int)(idx / mean_stride), ch = (int)(idx % mean_stride);
+    const long long row = (long long)(row_base_dev ? row_base_dev[0] : 0) + v;
+    if (ch >= c) {
+        if (mean && row < row_capacity) {
+            if (mean_dtype == PVX_F32) ((float*)mean)[row * mean_stride + ch] = 0.f;
+            else ((unsigned short*)mean)[row * mean_stride + ch] = 0;
+        }
+        return;
+    }
     const int* L = lists + (size_t)v * T;
     float sum = 0.f;
     int cnt = 0;
@@ -198,7 +214,20 @@ __global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restric
         sum += val;
     }
     if (ch == 0 && num_per_voxel) num_per_voxel[v] = cnt;
-    if (mean) mean[(size_t)v * c + ch] = sum / (float)(cnt < 1 ? 1 : cnt);
+    if (mean && row < row_capacity) {
+        const float m = sum / (float)(cnt < 1 ? 1 : cnt);
+        if (mean_dtype == PVX_F32) ((float*)mean)[row * mean_stride + ch] = m;
+        else if (mean_dtype == PVX_F16) ((_Float16*)mean)[row * mean_stride + ch] = (_Float16)m;
+        else ((__bf16*)mean)[row * mean_stride + ch] = (__bf16)m;
+    }
+}
+
+__global__ void vox_row_end_kernel(const int* __restrict__ num_voxels, const int* __restrict__ row_base_dev, int row_capacity,
+                                   int* __restrict__ row_end_dev) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long e = (long long)(row_base_dev ? row_base_dev[0] : 0) + num_voxels[0];
+        row_end_dev[0] = e < row_capacity ? (int)e : row_capacity;
+    }
 }
 
 __global__ __launch_bounds__(kBlk) void mean_vfe_kernel(const float* __restrict__ voxels, const int* __restrict__ num,
@@ -260,18 +289,32 @@ extern "C" size_t pvx_voxelize_hard_workspace_bytes(int n_points, int max_voxels
     return s.s.total();
 }
 
-extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
-                                 int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
-                                 int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+struct VoxOut {
+    float* voxels; int* coords_zyx; int* num_points_per_voxel; void* mean; int mean_stride; int mean_dtype;
+    int* point_to_voxel; int* num_voxels; int* coords_bzyx; int batch_idx; const int* row_base_dev; int row_capacity;
+    int* row_end_dev;
+};
+
+int voxelize_impl(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz, int max_points_per_voxel,
+                  int max_voxels, const VoxOut& o, void* workspace, size_t workspace_bytes, void* stream) {
+    float* voxels = o.voxels; int* coords_zyx = o.coords_zyx; int* num_points_per_voxel = o.num_points_per_voxel;
+    int* point_to_voxel = o.point_to_voxel; int* num_voxels = o.num_voxels;
     const int T = max_points_per_voxel;
-    if (n < 0 || c < 3 || T <= 0 || max_voxels <= 0 || !coords_zyx || !num_voxels || (n > 0 && !points)) return PVX_ERR_INVALID;
+    if (n < 0 || c < 3 || T <= 0 || max_voxels <= 0 || !num_voxels || (n > 0 && !points)) return PVX_ERR_INVALID;
     if ((long long)max_voxels * T > 0x7fffffffll) return PVX_ERR_RANGE;
     int grid[3];
     int rc = pvx_voxel_grid_size(vsize_xyz, range_xyz, grid);
     if (rc != PVX_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (n == 0) { PVX_CHECK_HIP(hipMemsetAsync(num_voxels, 0, sizeof(int), st)); return PVX_OK; }
+    if (n == 0) {
+        PVX_CHECK_HIP(hipMemsetAsync(num_voxels, 0, sizeof(int), st));
+        if (o.row_end_dev) {
+            hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
+            PVX_CHECK_LAUNCH();
+        }
+        return PVX_OK;
+    }
     VoxGeom g = { range_xyz[0], range_xyz[1], range_xyz[2], vsize_xyz[0], vsize_xyz[1], vsize_xyz[2], grid[0], grid[1], grid[2] };
     PvxCarver cv(workspace, workspace_bytes);
     VoxWorkspace w;
@@ -290,16 +333,46 @@ extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float*
     hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, max_voxels, num_voxels);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, w.keys, n,
-                       w.block_sums, g, max_voxels, w.vid_of_slot, coords_zyx);
+                       w.block_sums, g, max_voxels, w.vid_of_slot, coords_zyx, o.coords_bzyx, o.batch_idx, o.row_base_dev,
+                       o.row_capacity);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, T, max_voxels,
                        w.lists, point_to_voxel);
     PVX_CHECK_LAUNCH();
-    const long long work = (long long)max_voxels * c;
+    const long long work = (long long)max_voxels * o.mean_stride;
     hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk)), dim3(kBlk), 0, st, points, n, c, T,
-                       w.lists, num_voxels, voxels, num_points_per_voxel, mean);
+                       w.lists, num_voxels, voxels, num_points_per_voxel, o.mean, o.mean_stride, o.mean_dtype, o.row_base_dev,
+                       o.row_capacity);
     PVX_CHECK_LAUNCH();
+    if (o.row_end_dev) {
+        hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
+        PVX_CHECK_LAUNCH();
+    }
     return PVX_OK;
+}
+}  // namespace
+
+extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                                 int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
+                                 int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!coords_zyx) return PVX_ERR_INVALID;
+    VoxOut o = { voxels, coords_zyx, num_points_per_voxel, mean, c, PVX_F32, point_to_voxel, num_voxels, nullptr, 0, nullptr,
+                 max_voxels, nullptr };
+    return voxelize_impl(points, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pvx_voxelize_mean_append(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                                        int max_points_per_voxel, int max_voxels, int batch_idx, const int* row_base_dev,
+                                        int row_capacity, int* coords_bzyx, void* mean, int mean_stride, int mean_dtype,
+                                        int* num_voxels, int* row_end_dev, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    if (!coords_bzyx || !mean || !row_end_dev || row_capacity <= 0 || mean_stride < c || mean_dtype < 0 || mean_dtype > 2 ||
+        batch_idx < 0)
+        return PVX_ERR_INVALID;
+    VoxOut o = { nullptr, nullptr, nullptr, mean, mean_stride, mean_dtype, nullptr, num_voxels, coords_bzyx, batch_idx,
+                 row_base_dev, row_capacity, row_end_dev };
+    return voxelize_impl(points, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,

@@ -1,0 +1,365 @@
+"""Sync-free execution plan for the whole hot path of one batch of LiDAR frames:
+
+    raw points --voxelize + mean VFE--> sparse backbone (VoxelBackBone8x / VoxelResBackBone8x) --dense()--> BEV
+    decoded boxes --score sort--> batched rotated NMS
+
+The module API in `openpcdet_amd.spconv` mirrors spconv call for call and therefore reads one integer back per
+strided conv (a tensor SHAPE has to be known on the host).  This plan is what a deployment runs instead -- the role
+the reference gives to its SCN engine (libraries/3DSparseConvolution/libspconv/include/spconv/engine.hpp:58-104,
+fed by tool/centerpoint-export/export-scn.py): every buffer is allocated once at the configured CAPACITY, every
+data-dependent row count stays on the device (the `n_dev` arguments of the C ABI), eval-mode BatchNorm is folded into
+the conv epilogue exactly as the reference's exporter folds it (centerpoint-export/funcs.py:46-63,145-168), the two
+rulebooks the reference builds twice for one site set ('subm1' and 'res1', spconv_backbone.py:197-206) are built once,
+and the whole sequence of C-ABI launches contains no allocation and no host synchronisation, so it can be captured
+in a HIP graph and replayed.
+
+The arithmetic is the module path's: the same kernels, the same rulebooks; tests/test_gpu_engine.py checks one
+against the other.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .backbones import SparseBasicBlock
+from .spconv.pytorch.conv import SparseConvolution
+from .spconv.pytorch.modules import SparseSequential
+
+
+def _fold_bn(bn, cout, device):
+    """eval-mode BatchNorm1d as y = x * scale + shift (f32)."""
+    if bn is None:
+        return None, None
+    assert isinstance(bn, nn.BatchNorm1d) and bn.num_features == cout
+    var = bn.running_var.detach().float()
+    mean = bn.running_mean.detach().float()
+    g = bn.weight.detach().float() if bn.affine else torch.ones_like(var)
+    b = bn.bias.detach().float() if bn.affine else torch.zeros_like(var)
+    scale = g / torch.sqrt(var + bn.eps)
+    shift = b - mean * scale
+    return scale.to(device).contiguous(), shift.to(device).contiguous()
+
+
+class _ConvSpec:
+    """one fused conv launch: conv (+bias) -> folded BN -> (+residual) -> ReLU"""
+
+    def __init__(self, conv, bn, relu, residual):
+        self.conv, self.bn, self.relu, self.residual = conv, bn, relu, residual
+
+
+def _flatten_backbone(backbone):
+    """-> list of stages; a stage is a list of ('conv', _ConvSpec) / ('save',) / ('block', spec1, spec2) items in execution
+    order, recognised from the module tree the reference's backbones (and backbones.py) build."""
+    def seq_conv(seq):
+        mods = list(seq._modules.values())
+        assert isinstance(mods[0], SparseConvolution)
+        bn = mods[1] if len(mods) > 1 and isinstance(mods[1], nn.BatchNorm1d) else None
+        relu = any(isinstance(m, nn.ReLU) for m in mods[1:])
+        return _ConvSpec(mods[0], bn, relu, False)
+
+    stages = [[('conv', seq_conv(backbone.conv_input))]]
+    for name in ('conv1', 'conv2', 'conv3', 'conv4'):
+        items = []
+        for m in getattr(backbone, name)._modules.values():
+            if isinstance(m, SparseBasicBlock):
+                assert m.downsample is None
+                items.append(('block', _ConvSpec(m.conv1, m.bn1, True, False), _ConvSpec(m.conv2, m.bn2, True, True)))
+            elif isinstance(m, SparseSequential):
+                items.append(('conv', seq_conv(m)))
+            else:
+                raise TypeError("unrecognised backbone layer %r" % type(m))
+        stages.append(items)
+    stages.append([('conv', seq_conv(backbone.conv_out))])
+    return stages
+
+
+class _Level:
+    """one resolution level: coordinates, live row count, site index, submanifold rulebooks"""
+
+    def __init__(self, shape3, cap, batch, device, with_perm):
+        L = _lib.lib()
+        self.shape3, self.cap = list(shape3), int(cap)
+        self.c_shape = _lib.int3(shape3)
+        self.coords = torch.zeros((cap, 4), dtype=torch.int32, device=device)
+        self.n_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        nbytes = L.pvx_site_index_bytes(batch, self.c_shape)
+        if nbytes == 0:
+            raise ValueError("grid %s x batch %d is outside what the site index supports" % (shape3, batch))
+        self.index = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.perm = torch.empty(cap, dtype=torch.int32, device=device) if with_perm else None
+        self.ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, self.c_shape), device)
+        self.subm_nbr = {}    # (ksize tuple, dilation tuple) -> [K, cap] int32
+        self.bufs = {}        # channel count -> list of feature buffers
+
+
+class HotPathEngine:
+    def __init__(self, backbone, batch_size, point_cloud_range, voxel_size, max_points_per_voxel, max_voxels_per_frame,
+                 num_point_features, max_points_per_frame, dtype=torch.bfloat16, device="cuda", level_capacity_factor=1.5,
+                 want_dense=True):
+        """backbone: a VoxelBackBone8x / VoxelResBackBone8x (this package's or a state-dict-compatible tree) in eval mode.
+        level_capacity_factor: row capacity of each strided conv's output relative to its input's capacity (a k3 s2
+        conv emits at most 8 outputs per input site, typically ~1x on LiDAR data; rows beyond the capacity are dropped
+        and `overflowed()` reports it)."""
+        assert not backbone.training, "the plan folds BatchNorm running statistics: call backbone.eval() first"
+        assert dtype in _lib.DTYPE_CODE
+        self.L = _lib.lib()
+        self.device = torch.device(device)
+        self.dtype, self.code = dtype, _lib.DTYPE_CODE[dtype]
+        self.B = int(batch_size)
+        self.C = int(num_point_features)
+        self.T = int(max_points_per_voxel)
+        self.max_voxels = int(max_voxels_per_frame)
+        self.n_pts_cap = int(max_points_per_frame)
+        self.vsize = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
+        self.range = (ctypes.c_float * 6)(*[float(v) for v in point_cloud_range])
+        self.want_dense = want_dense
+        dev = self.device
+        with torch.cuda.device(dev):
+            self._build(backbone, level_capacity_factor)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _feat_buf(self, level, channels, avoid=()):
+        """a [cap, channels] buffer of `level` that is none of `avoid` (buffers are recycled within a level)"""
+        pool = level.bufs.setdefault(channels, [])
+        for b in pool:
+            if all(b is not a for a in avoid):
+                return b
+        b = torch.zeros((level.cap, channels), dtype=self.dtype, device=self.device)
+        pool.append(b)
+        return b
+
+    def _prep_weight(self, conv, cin_pad):
+        """kernel-ready weight, input channels zero-padded to cin_pad"""
+        L = self.L
+        cout, cin = conv.out_channels, conv.in_channels
+        kvol = int(np.prod(conv.kernel_size))
+        w = conv.weight.detach().to(self.device).float().reshape(cout, kvol, cin)
+        if cin_pad != cin:
+            w = torch.nn.functional.pad(w, (0, cin_pad - cin))
+        w = w.to(self.dtype).contiguous()
+        out = torch.empty(L.pvx_sparse_conv_weight_bytes(cout, kvol, cin_pad, self.code), dtype=torch.uint8, device=self.device)
+        _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), cout, kvol, cin_pad, self.code, _lib.ptr(out), _lib.stream()),
+                   "pvx_sparse_conv_prepare_weight")
+        return out
+
+    def _build(self, backbone, factor):
+        L, dev, B = self.L, self.device, self.B
+        stages = _flatten_backbone(backbone)
+        shape0 = [int(s) for s in backbone.sparse_shape]
+        grid = (ctypes.c_int * 3)()
+        _lib.check(L.pvx_voxel_grid_size(self.vsize, self.range, grid), "pvx_voxel_grid_size")
+        assert [grid[2] + 1, grid[1], grid[0]] == shape0, "voxel grid %s does not match the backbone's sparse_shape %s" % (
+            list(grid), shape0)
+
+        # input features: the first conv's input channels padded so that the MFMA kernel can take it
+        first = stages[0][0][1].conv
+        assert first.in_channels == self.C
+        self.cin0 = self.C
+        if self.dtype != torch.float32 and L.pvx_sparse_conv_uses_mfma(16, first.out_channels, self.code) and self.C <= 16:
+            self.cin0 = 16
+
+        lvl = _Level(shape0, B * self.max_voxels, B, dev, with_perm=True)
+        self.levels = [lvl]
+        self.feat0 = torch.zeros((lvl.cap, self.cin0), dtype=self.dtype, device=dev)
+        self.points = torch.full((B, self.n_pts_cap, self.C), float('nan'), dtype=torch.float32, device=dev)
+        self.num_voxels = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.vox_ws = _lib.workspace(L.pvx_voxelize_hard_workspace_bytes(self.n_pts_cap, self.max_voxels, self.T), dev)
+
+        self.ops = []          # (name, callable(stream))
+        self.conv_records = [] # per conv launch: dict(name, cin, cout, kvol, nbr, level_out) for flop accounting
+        keep = []              # keeps ctypes arrays / tensors alive
+        self._keep = keep
+        cur, cur_feat, cin_cur = lvl, self.feat0, self.cin0
+        self.stage_outputs = []
+
+        def add_subm_rulebook(level, conv):
+            key = (tuple(conv.kernel_size), tuple(conv.dilation))
+            if key in level.subm_nbr:
+                return level.subm_nbr[key]
+            kvol = int(np.prod(conv.kernel_size))
+            nbr = torch.empty((kvol, level.cap), dtype=torch.int32, device=dev)
+            level.subm_nbr[key] = nbr
+            k3, d3 = _lib.int3(conv.kernel_size), _lib.int3(conv.dilation)
+            keep.extend([k3, d3])
+            args = (_lib.ptr(level.coords), level.cap, _lib.ptr(level.n_dev), B, level.c_shape, _lib.ptr(level.index),
+                    _lib.ptr(level.perm), k3, d3, _lib.ptr(nbr))
+            self.ops.append(("subm_rulebook", lambda st, a=args: _lib.check(L.pvx_subm_rulebook(*a, st), "pvx_subm_rulebook")))
+            return nbr
+
+        def add_conv(spec, level_in, level_out, feat_in, cin, nbr, residual_buf, avoid):
+            conv = spec.conv
+            cout = conv.out_channels
+            kvol = int(np.prod(conv.kernel_size))
+            pw = self._prep_weight(conv, cin)
+            bias = conv.bias.detach().float().to(dev).contiguous() if conv.bias is not None else None
+            scale, shift = _fold_bn(spec.bn, cout, dev)
+            out = self._feat_buf(level_out, cout, avoid=avoid)
+            keep.extend([pw, bias, scale, shift])
+            args = (_lib.ptr(feat_in), level_in.cap, cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr), kvol, level_out.cap,
+                    _lib.ptr(level_out.n_dev), cout, self.code, _lib.ptr(scale), _lib.ptr(shift),
+                    _lib.ptr(residual_buf) if residual_buf is not None else None, 1 if spec.relu else 0, _lib.ptr(out))
+            name = "conv%d_%dx%d_k%d" % (len(self.conv_records), cin, cout, kvol)
+            self.ops.append((name, lambda st, a=args: _lib.check(L.pvx_sparse_conv_fwd(*a, st), "pvx_sparse_conv_fwd")))
+            self.conv_records.append(dict(name=name, cin=cin, cin_real=conv.in_channels, cout=cout, kvol=kvol, nbr=nbr,
+                                          level_out=level_out, subm=conv.subm))
+            return out, cout
+
+        # site index of the input level
+        self._n_unique0 = torch.zeros(1, dtype=torch.int32, device=dev)
+        a0 = (_lib.ptr(lvl.coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index), _lib.ptr(lvl.perm),
+              _lib.ptr(self._n_unique0), _lib.ptr(lvl.ws), lvl.ws.numel())
+        self.ops.append(("site_index", lambda st, a=a0: _lib.check(L.pvx_site_index_build(*a, st), "pvx_site_index_build")))
+
+        for stage in stages:
+            for item in stage:
+                if item[0] == 'conv':
+                    spec = item[1]
+                    conv = spec.conv
+                    assert not conv.inverse
+                    if conv.subm:
+                        nbr = add_subm_rulebook(cur, conv)
+                        cur_feat, cin_cur = add_conv(spec, cur, cur, cur_feat, cin_cur, nbr, None, avoid=(cur_feat,))
+                    else:
+                        k3, s3, p3, d3 = (_lib.int3(conv.kernel_size), _lib.int3(conv.stride), _lib.int3(conv.padding),
+                                          _lib.int3(conv.dilation))
+                        out3 = (ctypes.c_int * 3)()
+                        _lib.check(L.pvx_conv_out_shape(cur.c_shape, k3, s3, p3, d3, out3), "pvx_conv_out_shape")
+                        cells = B * out3[0] * out3[1] * out3[2]
+                        nxt = _Level([out3[0], out3[1], out3[2]], min(int(cur.cap * factor), cells), B, dev, with_perm=False)
+                        kvol = int(np.prod(conv.kernel_size))
+                        nbr = torch.empty((kvol, nxt.cap), dtype=torch.int32, device=dev)
+                        keep.extend([k3, s3, p3, d3, nbr])
+                        a1 = (_lib.ptr(cur.coords), cur.cap, _lib.ptr(cur.n_dev), B, cur.c_shape, k3, s3, p3, d3,
+                              _lib.ptr(nxt.index), _lib.ptr(nxt.n_dev), _lib.ptr(nxt.ws), nxt.ws.numel())
+                        a2 = (_lib.ptr(nxt.index), nxt.cap, _lib.ptr(nxt.n_dev), B, cur.c_shape, k3, s3, p3, d3,
+                              _lib.ptr(cur.index), _lib.ptr(cur.perm), _lib.ptr(nxt.coords), _lib.ptr(nbr))
+                        self.ops.append(("conv_out_index",
+                                         lambda st, a=a1: _lib.check(L.pvx_conv_out_index(*a, st), "pvx_conv_out_index")))
+                        self.ops.append(("conv_out_rulebook",
+                                         lambda st, a=a2: _lib.check(L.pvx_conv_out_rulebook(*a, st), "pvx_conv_out_rulebook")))
+                        cur_feat, cin_cur = add_conv(spec, cur, nxt, cur_feat, cin_cur, nbr, None, avoid=())
+                        self.levels.append(nxt)
+                        cur = nxt
+                else:   # residual block
+                    _, s1, s2 = item
+                    nbr = add_subm_rulebook(cur, s1.conv)
+                    identity = cur_feat
+                    mid, c_mid = add_conv(s1, cur, cur, cur_feat, cin_cur, nbr, None, avoid=(identity,))
+                    cur_feat, cin_cur = add_conv(s2, cur, cur, mid, c_mid, nbr, identity, avoid=(identity, mid))
+            self.stage_outputs.append((cur, cur_feat, cin_cur))
+            # a stage output handed to the caller must survive the following launches of the same level
+            cur.bufs[cin_cur] = [b for b in cur.bufs.get(cin_cur, []) if b is not cur_feat]
+        self.out_level, self.out_feat, self.out_channels = cur, cur_feat, cin_cur
+        if self.want_dense:
+            self.dense = torch.empty((B, self.out_channels, *cur.shape3), dtype=self.dtype, device=dev)
+            ad = (_lib.ptr(cur_feat), _lib.ptr(cur.coords), cur.cap, _lib.ptr(cur.n_dev), self.out_channels, self.code, B,
+                  cur.c_shape, _lib.ptr(self.dense))
+            self.ops.append(("dense", lambda st, a=ad: _lib.check(L.pvx_sparse_to_dense(*a, st), "pvx_sparse_to_dense")))
+        torch.cuda.synchronize(dev)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def load_points(self, frames):
+        """frames: list of B [n_b, C] float32 tensors (n_b <= max_points_per_frame); unused rows are NaN = dropped."""
+        assert len(frames) == self.B
+        for b, f in enumerate(frames):
+            n = f.shape[0]
+            assert n <= self.n_pts_cap and f.shape[1] == self.C
+            self.points[b, :n].copy_(f, non_blocking=True)
+            if n < self.n_pts_cap:
+                self.points[b, n:].fill_(float('nan'))
+
+    def voxelize(self, st=None):
+        L = self.L
+        st = _lib.stream() if st is None else st
+        lvl = self.levels[0]
+        lvl.n_dev.zero_()
+        for b in range(self.B):
+            _lib.check(L.pvx_voxelize_mean_append(self.points[b].data_ptr(), self.n_pts_cap, self.C, self.vsize, self.range,
+                                                  self.T, self.max_voxels, b, _lib.ptr(lvl.n_dev), lvl.cap,
+                                                  _lib.ptr(lvl.coords), _lib.ptr(self.feat0), self.cin0, self.code,
+                                                  self.num_voxels[b:b + 1].data_ptr(), _lib.ptr(lvl.n_dev),
+                                                  _lib.ptr(self.vox_ws), self.vox_ws.numel(), st), "pvx_voxelize_mean_append")
+
+    def backbone(self, st=None, hook=None):
+        st = _lib.stream() if st is None else st
+        if hook is None:
+            for _, fn in self.ops:
+                fn(st)
+        else:
+            for name, fn in self.ops:
+                hook(name, lambda: fn(st))
+
+    def forward(self):
+        """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
+        static buffer) or None.  No host synchronisation."""
+        with torch.cuda.device(self.device):
+            st = _lib.stream()
+            self.voxelize(st)
+            self.backbone(st)
+        if self.want_dense:
+            d = self.dense
+            return d.view(d.shape[0], d.shape[1] * d.shape[2], d.shape[3], d.shape[4])
+        return None
+
+    # ---- results (these DO synchronise: for tests / reporting, not for the hot loop) ---------------------------------
+    def level_rows(self):
+        return [int(l.n_dev.item()) for l in self.levels]
+
+    def overflowed(self):
+        """True when some level produced more rows than its capacity (rows were dropped)."""
+        return any(int(l.n_dev.item()) > l.cap for l in self.levels)
+
+    def stage_output(self, i):
+        """(indices [n, 4], features [n, C]) of stage i (0 = conv_input, 1..4 = x_conv1..4, 5 = conv_out)"""
+        lvl, feat, _ = self.stage_outputs[i]
+        n = min(int(lvl.n_dev.item()), lvl.cap)
+        return lvl.coords[:n], feat[:n]
+
+    def conv_flops(self):
+        """useful flops of one forward = sum over conv launches of 2 * P * Cin * Cout with P the number of valid
+        (input, output, offset) pairs of the launch's rulebook restricted to live rows."""
+        total, per = 0, []
+        for r in self.conv_records:
+            lvl = r["level_out"]
+            n = min(int(lvl.n_dev.item()), lvl.cap)
+            pairs = int((r["nbr"][:, :n] >= 0).sum().item())
+            f = 2 * pairs * r["cin_real"] * r["cout"]
+            per.append((r["name"], n, pairs, f))
+            total += f
+        return total, per
+
+
+class BatchedNMS:
+    """All (frame, head) NMS problems of a batch in one launch with static buffers (SURVEY.md H7;
+    pcdet/models/dense_heads/center_head.py:332-384 loops them in Python around
+    pcdet/models/model_utils/model_nms_utils.py:6-25)."""
+
+    def __init__(self, segments, cap, thresh, post_max, device="cuda", normal=False):
+        self.S, self.cap, self.thresh, self.post_max, self.normal = int(segments), int(cap), float(thresh), int(post_max), int(normal)
+        dev = torch.device(device)
+        self.device = dev
+        L = _lib.lib()
+        self.sorted_boxes = torch.zeros((self.S, self.cap, 7), dtype=torch.float32, device=dev)
+        self.keep = torch.zeros((self.S, self.cap), dtype=torch.int64, device=dev)
+        self.num = torch.zeros(self.S, dtype=torch.int32, device=dev)
+        self.ws = _lib.workspace(L.pvx_nms_workspace_bytes(self.cap, self.S), dev)
+        self._idx = torch.arange(self.cap, device=dev).unsqueeze(0)
+
+    def __call__(self, boxes, scores, counts):
+        """boxes [S, cap, >=7], scores [S, cap], counts [S] int32 -> (sel [S, post_max] int64 indices into each
+        segment's boxes in descending score order, num [S] int32 = min(kept, post_max)); no host sync."""
+        S, cap = self.S, self.cap
+        masked = torch.where(self._idx < counts.view(-1, 1), scores, scores.new_full((), float('-inf')))
+        order = masked.sort(1, descending=True)[1]
+        torch.gather(boxes[..., :7], 1, order.unsqueeze(-1).expand(S, cap, 7), out=self.sorted_boxes)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            _lib.check(L.pvx_nms_batched(_lib.ptr(self.sorted_boxes), _lib.ptr(counts), S, cap, self.thresh, self.normal,
+                                         _lib.ptr(self.keep), _lib.ptr(self.num), _lib.ptr(self.ws), self.ws.numel(),
+                                         _lib.stream()), "pvx_nms_batched")
+        k = self.keep[:, :self.post_max]
+        valid = self._idx[:, :self.post_max] < self.num.view(-1, 1)
+        sel = torch.gather(order, 1, torch.where(valid, k, torch.zeros_like(k)))
+        return sel, torch.clamp(self.num, max=self.post_max)
