@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""frames/s of the MI355X hot path: voxelize + mean VFE -> VoxelResBackBone8x (bf16, fp32 accumulate) -> dense BEV
+-> batched rotated NMS, on the nuScenes CenterPoint configuration (BASELINE.json configs[2], the configuration the
+metric is quoted on), frames sharded over the GPUs of one node with no data-path collective.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path over one batch of `--batch` synthetic frames per GPU (inputs already in HBM).
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      the dominant kernel (the implicit-GEMM sparse conv) priced from its algorithmic flops and its launch
+                durations measured with HIP events on the launching stream in an instrumented pass of the same plan
+  cpu_baseline  the CPU oracle (oracle/, a port: spconv itself cannot run here) timed on the host cores on a bounded sample
+  stages        per-stage device time of one step (ms), for orientation
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from openpcdet_amd import _lib, backbones, engine, synth  # noqa: E402
+
+WORKLOAD = "nuscenes_centerpoint"
+HEADS, BOXES_PER_HEAD, NMS_THRESH, NMS_POST = 6, 500, 0.2, 83   # cbgs_voxel0075_res3d_centerpoint.yaml:89-132
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def randomize_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data = torch.rand(m.num_features, generator=g) * 0.5 + 0.75
+            m.bias.data = torch.randn(m.num_features, generator=g) * 0.1
+            m.running_mean.data = torch.randn(m.num_features, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.num_features, generator=g) * 0.5 + 0.5
+
+
+def build_model(cfg, dev):
+    torch.manual_seed(11)
+    grid = [int(round((cfg["range"][3 + j] - cfg["range"][j]) / cfg["voxel"][j])) for j in range(3)]
+    net = backbones.VoxelResBackBone8x(input_channels=cfg["C"], grid_size=np.array(grid))
+    randomize_bn(net, 12)
+    return net.to(dev).eval()
+
+
+def make_inputs(cfg, rank, pool, dev):
+    frames = [torch.from_numpy(synth.config_cloud(WORKLOAD, 1000 * rank + 3 + i)).to(dev) for i in range(pool)]
+    S = HEADS
+    boxes = np.zeros((pool, S, BOXES_PER_HEAD, 9), np.float32)
+    scores = np.zeros((pool, S, BOXES_PER_HEAD), np.float32)
+    counts = np.zeros((pool, S), np.int32)
+    rng = np.random.default_rng(77 + rank)
+    for i in range(pool):
+        for s in range(S):
+            boxes[i, s], scores[i, s] = synth.boxes(BOXES_PER_HEAD, 9, cfg["range"], 5000 * rank + 10 * i + s, clustered=40)
+            counts[i, s] = rng.integers(300, BOXES_PER_HEAD + 1)
+    return frames, torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(counts).to(dev)
+
+
+def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts):
+    """the oracle chain on host cores: (frames/s, threads, description)"""
+    from oracle import chain, loader
+    threads = int(loader.oracle().orc_num_threads())
+    t_total = 0.0
+    for i in range(n_frames):
+        pts = synth.config_cloud(WORKLOAD, 3 + i)
+        t0 = time.perf_counter()
+        chain.backbone_chain(net_cpu, [pts], cfg)
+        chain.heads_nms(boxes[i], scores[i], counts[i], NMS_THRESH, NMS_POST)
+        t_total += time.perf_counter() - t0
+    return n_frames / t_total, threads, "%d full frames (300k points each), fp32, all stages; convs on %d OpenMP threads, " \
+        "voxelizer / rulebook / NMS single-threaded" % (n_frames, threads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per GPU")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--profile-passes", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm; used for the timing bracket only
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    cfg = synth.CONFIGS[WORKLOAD]
+    B, P = args.batch, max(args.pool, args.batch)
+    net = build_model(cfg, dev)
+    eng = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
+                               dtype=torch.bfloat16, device=dev, level_capacity_factor=2.0)
+    nms = engine.BatchedNMS(B * HEADS, BOXES_PER_HEAD, NMS_THRESH, NMS_POST, device=dev)
+    frames, boxes, scores, counts = make_inputs(cfg, rank, P, dev)
+    # static NMS inputs of one step (what the dense head would have decoded for the B frames)
+    s_boxes = torch.zeros((B * HEADS, BOXES_PER_HEAD, 9), device=dev)
+    s_scores = torch.zeros((B * HEADS, BOXES_PER_HEAD), device=dev)
+    s_counts = torch.zeros((B * HEADS,), dtype=torch.int32, device=dev)
+
+    def load(step):
+        for b in range(B):
+            i = (step * B + b) % P
+            eng.points[b].copy_(frames[i])
+            s_boxes[b * HEADS:(b + 1) * HEADS].copy_(boxes[i])
+            s_scores[b * HEADS:(b + 1) * HEADS].copy_(scores[i])
+            s_counts[b * HEADS:(b + 1) * HEADS].copy_(counts[i])
+
+    result = {}
+
+    def note(msg):
+        if rank == 0 and os.environ.get("BENCH_VERBOSE"):
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    def hot_path():
+        eng.forward()
+        result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+
+    graph = None
+    note("inputs ready")
+    load(0)
+    torch.cuda.synchronize()
+    note("loaded")
+    eng.voxelize()
+    torch.cuda.synchronize()
+    note("voxelized, rows %s" % eng.level_rows()[:1])
+    eng.backbone(hook=(lambda name, fn: (fn(), torch.cuda.synchronize(), note("  " + name))) if os.environ.get("BENCH_VERBOSE") else None)
+    torch.cuda.synchronize()
+    note("backbone done, rows %s" % eng.level_rows())
+    hot_path()   # whole path once, eagerly, before any capture
+    torch.cuda.synchronize()
+    note("eager pass done")
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            hot_path()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hot_path()
+        note("graph captured")
+
+    def step(i):
+        load(i)
+        if graph is not None:
+            graph.replay()
+        else:
+            hot_path()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    note("timed region done: %.3f s" % elapsed)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert not eng.overflowed(), "a level overflowed its row capacity"
+    rows = eng.level_rows()
+
+    out = None
+    if rank == 0:
+        # ---- instrumented pass: HIP events around every launch of the plan, on the stream they are launched on ----
+        ev = {}
+
+        def hook(name, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ev.setdefault(name, []).append((a, b))
+
+        stage_ev = {}
+
+        def timed(name, fn):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            stage_ev.setdefault(name, []).append((a, b))
+
+        for p in range(args.profile_passes + 1):
+            load(p)
+            if p == 1:          # pass 0 is a warm-up of the eager path
+                ev.clear()
+                stage_ev.clear()
+            timed("voxelize", eng.voxelize)
+            eng.backbone(hook=hook)
+            timed("nms", lambda: nms(s_boxes, s_scores, s_counts))
+        torch.cuda.synchronize()
+        passes = args.profile_passes
+        conv_ms = sum(a.elapsed_time(b) for n, l in ev.items() if n.startswith("conv") and not n.startswith("conv_out") for a, b in l) / passes
+        conv_launches = sum(1 for n in ev if n.startswith("conv") and not n.startswith("conv_out"))
+        rule_ms = sum(a.elapsed_time(b) for n, l in ev.items() if n in ("site_index", "subm_rulebook", "conv_out_index", "conv_out_rulebook") for a, b in l) / passes
+        dense_ms = sum(a.elapsed_time(b) for a, b in ev.get("dense", [])) / passes
+        vox_ms = sum(a.elapsed_time(b) for a, b in stage_ev["voxelize"]) / passes
+        nms_ms = sum(a.elapsed_time(b) for a, b in stage_ev["nms"]) / passes
+        flops, per_layer = eng.conv_flops()     # of the last loaded batch
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": None,
+                    "kernel": "sparse_conv_mfma_kernel (%d launches/step)" % conv_launches,
+                    "flops_per_step": flops, "ms_per_step": round(conv_ms, 4)}
+        cpu = None
+        if args.cpu_frames > 0:
+            v, threads, sample = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(),
+                                              counts.cpu().numpy())
+            cpu = {"value": round(v, 4), "unit": "frames/s", "cores": threads, "kind": "port", "sample": sample}
+        value = world * B * args.steps / elapsed
+        out = {
+            "metric": "frames/sec voxelize+sparse backbone+NMS (nuScenes CenterPoint)",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CenterPoint nuScenes 10-sweep 300k pts/frame, 0.075 m voxels, VoxelResBackBone8x, "
+                                   "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
+                       "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
+                       "hip_graph": graph is not None, "rows_per_level": rows},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
+                       "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},
+        }
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -96,12 +96,14 @@ class _Level:
 
 class HotPathEngine:
     def __init__(self, backbone, batch_size, point_cloud_range, voxel_size, max_points_per_voxel, max_voxels_per_frame,
-                 num_point_features, max_points_per_frame, dtype=torch.bfloat16, device="cuda", level_capacity_factor=1.5,
+                 num_point_features, max_points_per_frame, dtype=torch.bfloat16, device="cuda", level_capacity_factor=None,
                  want_dense=True):
         """backbone: a VoxelBackBone8x / VoxelResBackBone8x (this package's or a state-dict-compatible tree) in eval mode.
-        level_capacity_factor: row capacity of each strided conv's output relative to its input's capacity (a k3 s2
-        conv emits at most 8 outputs per input site, typically ~1x on LiDAR data; rows beyond the capacity are dropped
-        and `overflowed()` reports it)."""
+        level_capacity_factor: row capacity of each strided conv's output relative to its input's capacity.  None (the
+        default) sizes every level for the worst case, prod_j ceil(k_j / s_j) outputs per input site (8 for k3 s2),
+        capped by the number of grid cells -- never overflows, costs memory and idle workgroups.  Dense LiDAR frames give
+        ~1x, isolated voxels up to ~3.4x; with an explicit factor, rows beyond the capacity are dropped and
+        `overflowed()` reports it."""
         assert not backbone.training, "the plan folds BatchNorm running statistics: call backbone.eval() first"
         assert dtype in _lib.DTYPE_CODE
         self.L = _lib.lib()
@@ -227,7 +229,9 @@ class HotPathEngine:
                         out3 = (ctypes.c_int * 3)()
                         _lib.check(L.pvx_conv_out_shape(cur.c_shape, k3, s3, p3, d3, out3), "pvx_conv_out_shape")
                         cells = B * out3[0] * out3[1] * out3[2]
-                        nxt = _Level([out3[0], out3[1], out3[2]], min(int(cur.cap * factor), cells), B, dev, with_perm=False)
+                        worst = int(np.prod([-(-k // s) for k, s in zip(conv.kernel_size, conv.stride)]))
+                        f = worst if factor is None else min(float(factor), worst)
+                        nxt = _Level([out3[0], out3[1], out3[2]], max(1, min(int(cur.cap * f), cells)), B, dev, with_perm=False)
                         kvol = int(np.prod(conv.kernel_size))
                         nbr = torch.empty((kvol, nxt.cap), dtype=torch.int32, device=dev)
                         keep.extend([k3, s3, p3, d3, nbr])

@@ -26,6 +26,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 static uint64_t mix64s(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
@@ -169,6 +172,9 @@ void orc_inverse_rulebook(const int* nbr_fwd, int K, int n_out_fwd, int n_in_fwd
 /* out[o, :] = bias + sum_k W[:, k, :] . feat[nbr[k][o], :]   (binary32, k ascending, then cin ascending) */
 void orc_sparse_conv_fwd(const float* feat, int cin, const float* weight, const float* bias, const int* nbr, int K,
                          int n_out, int cout, float* out) {
+    /* rows are independent: threads split the rows, every row's sum keeps its sequential order (bit-identical
+     * for any thread count) */
+#pragma omp parallel for schedule(dynamic, 256)
     for (int o = 0; o < n_out; o++) {
         for (int co = 0; co < cout; co++) {
             float acc = 0.f;
@@ -182,6 +188,15 @@ void orc_sparse_conv_fwd(const float* feat, int cin, const float* weight, const 
             out[(size_t)o * cout + co] = acc + (bias ? bias[co] : 0.f);
         }
     }
+}
+
+/* threads orc_sparse_conv_fwd runs on (1 when built without OpenMP) */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* number of valid (input, output, offset) pairs: defines the useful flops 2 * P * Cin * Cout */
