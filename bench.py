@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per GPU")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
+                    "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
@@ -150,7 +151,7 @@ def main():
     hot_path()   # whole path once, eagerly, before any capture
     torch.cuda.synchronize()
     note("eager pass done")
-    if not args.no_graph:
+    if args.graph:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
