@@ -24,6 +24,7 @@
 //   * Cin = 16 packs TWO kernel offsets into one K=32 MFMA step.
 // Generic path (fp32, or channel counts the MFMA tiling does not cover): one thread per (site, cout), fp32 math.
 #include "pvx_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,7 +77,7 @@ __host__ __device__ inline bool frag_source(int g, int s, int t, int l, int j, i
     typedef Tiling<CIN, COUT> TL;
     const int r = l & 15, G = l >> 4;
     co = (r >> 2) * (COUT / 4) + 4 * t + (r & 3);
-    if (CIN >= 32) { k = g; ci = G * (CIN / 4) + 8 * s + j; }
+    if (CIN >= 32) { k = g; ci = 32 * s + 8 * G + j; }
     else { k = TL::OFFS * g + (G >> 1); ci = 8 * (G & 1) + j; }
     return k < K;
 }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(kBlk) void sparse_conv_mfma_kernel(const E* __restr
     const int site0 = (blockIdx.x * 4 + wave) * (16 * MT);     // first site of this wave
     const int n_live = live_rows(n_out, n_out_dev);            // n_out stays the row stride of nbr
     if (blockIdx.x * 4 * 16 * MT >= n_live) return;            // whole workgroup beyond the live rows
-    const int chan0 = CIN >= 32 ? G * (CIN / 4) : 8 * (G & 1); // first input channel of this lane's pieces
+    const int chan0 = CIN >= 32 ? 8 * G : 8 * (G & 1);         // first input channel of this lane's piece of step 0
 
     f32x4 acc[MT][T];
 #pragma unroll
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlk) void sparse_conv_mfma_kernel(const E* __restr
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (rows[m] >= 0) v = *reinterpret_cast<const uint4*>(feat + (size_t)rows[m] * CIN + chan0 + 8 * s);
+                    if (rows[m] >= 0) v = *reinterpret_cast<const uint4*>(feat + (size_t)rows[m] * CIN + chan0 + 32 * s);
                     b[s][m] = v;
                 }
 #pragma unroll
@@ -264,6 +265,291 @@ __global__ __launch_bounds__(kBlk) void sparse_conv_mfma_kernel(const E* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MFMA kernel, pipelined form (used whenever K <= kMaxKLds and the feature buffer is < 2 GiB)
+//
+//   * the tile's rulebook slice nbr[K][TM] is staged into LDS once, validated (row < n_in, site < live rows), so the
+//     main loop's index reads are LDS broadcasts instead of a dependent global load per offset;
+//   * feature rows are gathered with buffer loads whose range check turns an invalid neighbour into zeros -- no
+//     branch around a load -- into a ring of D register sets: the gathers of D-1 offsets stay in flight behind the
+//     MFMAs of the current one.  Small channel counts are gather-latency bound and keep the WHOLE kernel volume in
+//     flight (D = number of offset groups); wide layers are MFMA-bound and use D = 2..4;
+//   * weights: RESIDENT = the whole layer lives in LDS and the workgroup is persistent over site tiles (these layers
+//     must not pay a weight reload per tile); otherwise 32-KiB chunks are streamed through two LDS buffers,
+//     global -> registers while the previous chunk's MFMAs run, registers -> LDS behind them, ONE barrier per chunk;
+//   * the main loop is straight-line MFMA code: the only branch is the wave-uniform "no site of this wave has a
+//     neighbour at this offset" skip of a whole group.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxKLds = 32;
+constexpr int kResidentBytes = 112 * 1024;
+
+// diagnostic build only (PVX_ABLATE bit 32): per-workgroup cycle sums of the tile phases, read back by pvx_debug_conv_stamps
+__device__ unsigned long long g_conv_stamps[1024 * 8];
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int CIN, int COUT, int NT> struct Plan {
+    typedef Tiling<CIN, COUT> TL;
+    static constexpr int GROUP_BYTES = TL::GROUP_U4 * 16;
+    static constexpr int GPC = (32768 / GROUP_BYTES) > 0 ? (32768 / GROUP_BYTES) : 1;   // groups per streamed chunk
+    static constexpr int CHUNK_U4 = GPC * TL::GROUP_U4;
+    static constexpr int WREG = (CHUNK_U4 + NT - 1) / NT;
+    static constexpr int RES_GROUPS = (27 + TL::OFFS - 1) / TL::OFFS;                    // resident form: K <= 27
+    static constexpr int RES_U4 = RES_GROUPS * TL::GROUP_U4;
+    static constexpr bool CAN_RESIDE = RES_U4 * 16 <= kResidentBytes;
+};
+
+template <typename E, int CIN, int COUT, int MT, int D, bool RESIDENT, int NT>
+__global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
+                                                               const uint4* __restrict__ wfrag, const int* __restrict__ nbr,
+                                                               int K, int n_out, const int* __restrict__ n_out_dev,
+                                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const E* __restrict__ residual,
+                                                               int relu, E* __restrict__ out, int dbg) {
+    typedef Tiling<CIN, COUT> TL;
+    typedef Plan<CIN, COUT, NT> PL;
+    constexpr int T = TL::T, S = TL::S, TM = (NT / 64) * 16 * MT;
+    constexpr int W_U4 = RESIDENT ? PL::RES_U4 : 2 * PL::CHUNK_U4;
+    __shared__ uint4 wlds[W_U4];
+    __shared__ int nlds[kMaxKLds * TM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, G = lane >> 4;
+    const int n_live = live_rows(n_out, n_out_dev);
+    const int ntiles = (n_live + TM - 1) / TM;
+    // XCD-aware tile order (speed only, never correctness): workgroups b and b + 8 share an XCD and its 4-MiB L2, so
+    // XCD x walks the x-th CONTIGUOUS eighth of the tiles with its workgroups on consecutive tiles.  Rows are in
+    // ascending (b, z, y, x) key order, so at any moment an XCD's gathers fall into three narrow row windows
+    // (z - 1, z, z + 1) that fit its L2, instead of every XCD streaming the whole feature table past its L2.
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7) >> 3;
+    const int tile_begin = (int)((long long)ntiles * xcd / 8), tile_end = (int)((long long)ntiles * (xcd + 1) / 8);
+    if (tile_begin + wg_in_xcd >= tile_end) return;            // whole workgroup: no barrier is skipped by part of it
+    const int ngroups = TL::groups(K);
+    const int total_u4 = ngroups * TL::GROUP_U4;
+    const int ls = lane >> 2, lq = lane & 3;                    // loading role: site within the subtile, 16-B piece
+    const unsigned piece_off = (unsigned)((CIN >= 32 ? lq : (lq & 1)) * 16);
+    const int perm_addr = (4 * r16 + G) * 4;                    // ds_bpermute source lane (as a byte address)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+
+    // all staging copies below are written "issue every load, then every store": a load / wait / store loop would pay
+    // one full memory latency per iteration
+    if (RESIDENT) {
+        constexpr int NW = (PL::RES_U4 + NT - 1) / NT;
+        uint4 tmp[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (q * NT + tid < total_u4) v = wfrag[q * NT + tid];
+            tmp[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NW; q++) if (q * NT + tid < total_u4) wlds[q * NT + tid] = tmp[q];
+    }
+
+    unsigned long long st_sum[5] = {0, 0, 0, 0, 0};
+    for (int tile = tile_begin + wg_in_xcd; tile < tile_end; tile += wgs_per_xcd) {
+        const int tile0 = tile * TM;
+        unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;
+        if (dbg & 32) st0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();   // the previous tile is done with nlds / wlds
+        if (dbg & 32) st1 = __builtin_amdgcn_s_memtime();
+        {
+            constexpr int NI = kMaxKLds * TM / NT;
+            int tmp[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                const int k = i / TM, site = tile0 + (i - k * TM);
+                int v = -1;
+                if (k < K && site < n_live && !(dbg & 16)) v = nbr[(size_t)k * n_out + site];
+                tmp[q] = v;
+            }
+            uint4 wtmp[RESIDENT ? 1 : PL::WREG];
+            if (!RESIDENT) {
+#pragma unroll
+                for (int q = 0; q < PL::WREG; q++) {
+                    const int i = q * NT + tid;
+                    if (i < PL::CHUNK_U4 && i < total_u4) wtmp[q] = wfrag[i];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                if (i < K * TM) nlds[i] = tmp[q] >= n_in ? -1 : tmp[q];
+            }
+            if (!RESIDENT) {
+#pragma unroll
+                for (int q = 0; q < PL::WREG; q++) {
+                    const int i = q * NT + tid;
+                    if (i < PL::CHUNK_U4 && i < total_u4) wlds[i] = wtmp[q];
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg & 32) st2 = __builtin_amdgcn_s_memtime();
+
+        f32x4 acc[MT][T];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int t = 0; t < T; t++) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 ring[D][S][MT];
+        int act[D];
+        uint4 wreg[RESIDENT ? 1 : PL::WREG];
+        const int* my_n = nlds + wave * (16 * MT) + ls;
+
+        // gathers of group g into one register set; act != 0 <=> some site of the wave has a valid neighbour.
+        // Lane roles while LOADING: lane = 4 * site + q, the 4 lanes of a site read 64 contiguous bytes of its row
+        // (CIN = 16: 2 lanes per (site, offset) row of 32 B), so the vector memory pipe sees one 64-B access per four
+        // lanes; compute() moves each 16-B piece to the lane the MFMA wants it in (16 * q + site) with ds_bpermute.
+        auto issue = [&](int g, u32x4 (&b)[S][MT], int& a) {
+            const int koff = CIN >= 32 ? g : TL::OFFS * g + (lq >> 1);
+            bool any = false;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const int rr = koff < K ? my_n[koff * TM + m * 16] : -1;
+                const unsigned voff = rr >= 0 ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + piece_off : feat_bytes;
+                any |= rr >= 0;
+#pragma unroll
+                for (int s = 0; s < S; s++) b[s][m] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 64 * s, 0, 0);
+            }
+            a = __builtin_amdgcn_readfirstlane(__ballot(any) != 0ull ? 1 : 0);
+        };
+        // LDS side of a stage: stage (g, q) covers K-step s = q / H and cout half h = q % H of offset group g.  fetch()
+        // requests its weight fragments (and, on the first half of a K-step, the ds_bpermute'd feature fragments);
+        // the main loop always has the NEXT stage's fetch in flight behind the CURRENT stage's MFMAs, across group
+        // boundaries too (two register sets, parity known at compile time because D is even).
+        static_assert(D % 2 == 0, "ring depth must be even");
+        constexpr int H = T > 4 ? 2 : 1, TT = T / H, NQ = S * H;
+        uint4 wa[2][TT], fb[2][MT];
+        auto wbase = [&](int g) -> const uint4* {
+            if (RESIDENT) return wlds + g * TL::GROUP_U4 + lane;
+            const int c = g / PL::GPC, gl = g - c * PL::GPC;
+            return wlds + (c & 1) * PL::CHUNK_U4 + gl * TL::GROUP_U4 + lane;
+        };
+        auto fetch = [&](const uint4* wsrc, const u32x4 (&b)[S][MT], int q, uint4 (&w)[TT], uint4 (&ff)[MT]) {
+            const int s = q / H, h = q - s * H;
+            if (h == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    ff[m].x = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)b[s][m].x);
+                    ff[m].y = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)b[s][m].y);
+                    ff[m].z = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)b[s][m].z);
+                    ff[m].w = (unsigned)__builtin_amdgcn_ds_bpermute(perm_addr, (int)b[s][m].w);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; t++) w[t] = wsrc[(s * T + h * TT + t) * 64];
+        };
+
+#pragma unroll
+        for (int j = 0; j < D - 1; j++)
+            if (j < ngroups) issue(j, ring[j], act[j]);
+        if (act[0] != 0 && !(dbg & 1)) fetch(wbase(0), ring[0], 0, wa[0], fb[0]);
+        for (int g0 = 0; g0 < ngroups; g0 += D) {
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+                const int g = g0 + j;
+                if (g < ngroups) {
+                    const int jn = (j + 1) % D;   // constant after unrolling
+                    if (g + D - 1 < ngroups) issue(g + D - 1, ring[(j + D - 1) % D], act[(j + D - 1) % D]);
+                    if (!RESIDENT && g % PL::GPC == 0 && !(dbg & 2)) {
+                        // first group of chunk c: fetch chunk c+1 into registers, ahead of this chunk's MFMAs
+                        const int next0 = (g / PL::GPC + 1) * PL::CHUNK_U4;
+                        if (next0 < total_u4) {
+#pragma unroll
+                            for (int q = 0; q < PL::WREG; q++) {
+                                const int i = q * NT + tid;
+                                if (i < PL::CHUNK_U4 && next0 + i < total_u4) wreg[q] = wfrag[next0 + i];
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    const bool on = act[j] != 0 && !(dbg & 1);
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int p = (j * NQ + q) & 1, fs = (j * S + q / H) & 1;
+                        if (q + 1 < NQ) {
+                            if (on) fetch(wbase(g), ring[j], q + 1, wa[p ^ 1], fb[(j * S + (q + 1) / H) & 1]);
+                        } else if (g + 1 < ngroups) {
+                            if (!RESIDENT && (g + 1) % PL::GPC == 0) {
+                                // the next group opens chunk c+1: registers -> LDS buffer (c+1)&1 (last read during chunk
+                                // c-1, and every wave is past the barrier that closed it), ONE barrier, then its fetch
+                                const int c1 = (g + 1) / PL::GPC;
+                                if (!(dbg & 2)) {
+                                    uint4* dst = wlds + (c1 & 1) * PL::CHUNK_U4;
+#pragma unroll
+                                    for (int qq = 0; qq < PL::WREG; qq++) {
+                                        const int i = qq * NT + tid;
+                                        if (i < PL::CHUNK_U4 && c1 * PL::CHUNK_U4 + i < total_u4) dst[i] = wreg[qq];
+                                    }
+                                }
+                                if (!(dbg & 4)) __syncthreads();
+                            }
+                            if (act[jn] != 0 && !(dbg & 1)) fetch(wbase(g + 1), ring[jn], 0, wa[p ^ 1], fb[((j + 1) * S) & 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (on) {
+                            const int h = q % H;
+#pragma unroll
+                            for (int t = 0; t < TT; t++)
+#pragma unroll
+                                for (int m = 0; m < MT; m++)
+                                    acc[m][h * TT + t] = Mfma<E>::run(wa[p][t], fb[fs][m], acc[m][h * TT + t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+
+        if (dbg & 32) st3 = __builtin_amdgcn_s_memtime();
+        // epilogue: lane holds, for site (tile0 + wave*16*MT + m*16 + r16), couts G*(COUT/4) + 4t + reg
+        const int co0 = G * (COUT / 4);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const int site = tile0 + wave * (16 * MT) + m * 16 + r16;
+            if (site >= n_live) continue;
+            const size_t base = (size_t)site * COUT + co0;
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = acc[m][t][q];
+                if (bias) {
+                    const float4 bb = *reinterpret_cast<const float4*>(bias + co0 + 4 * t);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (scale) {
+                    const float4 sc = *reinterpret_cast<const float4*>(scale + co0 + 4 * t);
+                    const float4 sh = *reinterpret_cast<const float4*>(shift + co0 + 4 * t);
+                    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+                }
+                if (residual) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(residual + base + 4 * t);
+                    E re[4];
+                    __builtin_memcpy(re, &rr, 8);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) v[q] += (float)re[q];
+                }
+                E oe[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) oe[q] = (E)(relu ? fmaxf(v[q], 0.f) : v[q]);
+                uint2 packed;
+                __builtin_memcpy(&packed, oe, 8);
+                *reinterpret_cast<uint2*>(out + base + 4 * t) = packed;
+            }
+        }
+        if (dbg & 32) {
+            st4 = __builtin_amdgcn_s_memtime();
+            st_sum[0] += st1 - st0; st_sum[1] += st2 - st1; st_sum[2] += st3 - st2; st_sum[3] += st4 - st3; st_sum[4] += 1;
+        }
+    }
+    if ((dbg & 32) && tid == 0 && blockIdx.x < 1024) {
+        for (int q = 0; q < 5; q++) g_conv_stamps[blockIdx.x * 8 + q] = st_sum[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // dense(): out[b, c, z, y, x] = feat[i, c]; thread = (site, channel) with the SITE index fastest so that
 // neighbouring lanes (rows in ascending key order = adjacent x) write adjacent addresses of one channel plane
 // ---------------------------------------------------------------------------------------------------
@@ -310,10 +596,80 @@ long long prepared_elems(int cout, int K, int cin, int dtype) {
     return (long long)cout * K * cin;
 }
 
+int num_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
+}
+
+// timing-only ablation (cdna_hip_programming.md section 7): PVX_ABLATE_GATHER=1 gives the feature buffer descriptor
+// zero records, so every gather is dropped by the range check while the instruction stream stays (results are wrong)
+bool ablate_gather() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PVX_ABLATE_GATHER"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+// PVX_ABLATE=<bits>: 1 no MFMA block, 2 no weight streaming, 4 no main-loop barriers, 8 no epilogue stores, 16 no
+// rulebook staging loads.  Timing experiments only (results are wrong); 0 / unset in production.
+int ablate_bits() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PVX_ABLATE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <typename E, int CIN, int COUT>
 int launch_mfma(const void* feat, int n_in, const void* w, const int* nbr, int K, int n_out, const int* n_out_dev,
                 const float* bias, const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
-    // bigger site tiles amortise the weight staging; smaller ones keep >= ~2 workgroups per CU on small levels
+    unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
+    if (ablate_gather() && feat_bytes < 0x80000000ull) feat_bytes = 0;
+    constexpr bool kPipelined = Plan<CIN, COUT, 512>::GROUP_BYTES <= 32768;   // one (offset, all couts) slab per 32-KiB chunk
+    if constexpr (kPipelined) if (K <= kMaxKLds && feat_bytes < 0x80000000ull) {
+        if constexpr (Plan<CIN, COUT, 512>::CAN_RESIDE) {
+          if (K <= 27) {
+            // gather-bound layers: persistent workgroups of 8 waves x 16 sites, weights resident in LDS, every offset's
+            // gathers in flight at once; as many workgroups as the LDS of the chip holds
+            typedef Plan<CIN, COUT, 512> PL;
+            constexpr int NT = 512, MT = 1, TM = (NT / 64) * 16 * MT;
+            const int lds = PL::RES_U4 * 16 + kMaxKLds * TM * 4;
+            constexpr int D = 6;   // <= 128 VGPRs: two 8-wave workgroups per CU
+            static int per_cu = 0;   // what the chip actually admits (LDS and VGPRs), asked once per instantiation
+            if (per_cu == 0) {
+                int nb = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_conv_mfma2_kernel<E, CIN, COUT, MT, D, true, NT>, NT, 0) !=
+                        hipSuccess || nb < 1) nb = 1;
+                per_cu = nb > 2 ? 2 : nb;
+            }
+            (void)lds;
+            int grid = num_cus() * per_cu;
+            const int tiles = PVX_CDIV(n_out, TM);
+            if (grid > tiles) grid = (tiles + 7) / 8 * 8;
+            hipLaunchKernelGGL((sparse_conv_mfma2_kernel<E, CIN, COUT, MT, D, true, NT>), dim3(grid), dim3(NT), 0, st,
+                               (const E*)feat, n_in, (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale,
+                               shift, (const E*)residual, relu, (E*)out, ablate_bits());
+            return PVX_OK;
+          }
+        }
+        {
+            // MFMA-bound layers: 8 waves x 32 sites, weights streamed in 32-KiB chunks shared by the 8 waves
+            constexpr int NT = 512, MT = 2, TM = (NT / 64) * 16 * MT;
+            constexpr int D = CIN >= 128 ? 2 : (CIN >= 64 ? 4 : 6);
+            // one 8-wave workgroup per CU (96 KiB of LDS), looping over the live tiles: the grid does not grow with
+            // the row CAPACITY, so no dead workgroups are dispatched
+            int grid = num_cus();
+            const int tiles = PVX_CDIV(n_out, TM);
+            if (grid > tiles) grid = (tiles + 7) / 8 * 8;
+            hipLaunchKernelGGL((sparse_conv_mfma2_kernel<E, CIN, COUT, MT, D, false, NT>), dim3(grid), dim3(NT), 0, st,
+                               (const E*)feat, n_in, (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale,
+                               shift, (const E*)residual, relu, (E*)out, ablate_bits());
+        }
+        return PVX_OK;
+    }
+    // large kernels (K > 32, e.g. 5x5x5) or > 2 GiB feature buffers: the simple form
     const int blocks2 = PVX_CDIV(n_out, 4 * 16 * 2);
     if (blocks2 >= 512) {
         hipLaunchKernelGGL((sparse_conv_mfma_kernel<E, CIN, COUT, 2>), dim3(blocks2), dim3(kBlk), 0, st, (const E*)feat, n_in,
@@ -338,6 +694,12 @@ int launch_generic(const void* feat, int n_in, int cin, const void* w, const int
 }
 
 }  // namespace
+
+extern "C" int pvx_debug_conv_stamps(unsigned long long* host_out, int n_words) {
+    if (!host_out || n_words <= 0 || n_words > 1024 * 8) return PVX_ERR_INVALID;
+    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_stamps), (size_t)n_words * sizeof(unsigned long long)));
+    return PVX_OK;
+}
 
 extern "C" int pvx_sparse_conv_uses_mfma(int cin, int cout, int dtype) { return mfma_shape(cin, cout, dtype) ? 1 : 0; }
 
