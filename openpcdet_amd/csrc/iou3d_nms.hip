@@ -96,6 +96,9 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
     __shared__ float rawcol[64 * 7];
     __shared__ float rawrow[64 * 7];
     __shared__ VertexScratch vs;
+    __shared__ unsigned long long words[64];
+    __shared__ unsigned short queue[64 * 64];
+    __shared__ int qcount;
 
     const float* seg_boxes = boxes + (size_t)seg * n_cap * 7;
     unsigned long long* seg_mask = mask + (size_t)seg * n_cap * cb_cap;
@@ -115,39 +118,56 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
             }
         }
     }
+    if (tid < 64) words[tid] = 0ull;
+    if (tid == 0) qcount = 0;
     __syncthreads();
 
-    const int col = C * 64 + lane;
-    const bool col_ok = col < n;
-    PvxBoxRec B;
-    float braw[7];
-    if (col_ok) {
-        if (NORMAL) {
+    if (NORMAL) {
+        // axis-aligned IoU is a handful of flops: one ballot per row, no candidate queue
+        const int col = C * 64 + lane;
+        const bool col_ok = col < n;
+        float braw[7];
+        if (col_ok) {
 #pragma unroll
             for (int k = 0; k < 7; k++) braw[k] = rawcol[lane * 7 + k];
-        } else {
-            B = colrec[lane];
         }
-    }
 #pragma unroll 1
-    for (int r = 0; r < 16; r++) {
-        const int rt = wave * 16 + r;          // row inside the tile (wave-uniform)
-        const int row = R * 64 + rt;
-        if (row >= n) break;                   // wave-uniform exit
-        bool bit = false;
-        if (col_ok && (R != C || lane > rt)) {
-            float v;
-            if (NORMAL) {
-                v = pvx_iou_normal(rawrow + rt * 7, braw);
-            } else {
-                const PvxBoxRec A = rowrec[rt];
-                v = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock));
-            }
-            bit = v > thresh;
+        for (int r = 0; r < 16; r++) {
+            const int rt = wave * 16 + r;          // row inside the tile (wave-uniform)
+            const int row = R * 64 + rt;
+            if (row >= n) break;                   // wave-uniform exit
+            bool bit = false;
+            if (col_ok && (R != C || lane > rt)) bit = pvx_iou_normal(rawrow + rt * 7, braw) > thresh;
+            const unsigned long long word = __ballot(bit);
+            if (lane == 0) seg_mask[(size_t)row * cb_cap + C] = word;
         }
-        const unsigned long long word = __ballot(bit);
-        if (lane == 0) seg_mask[(size_t)row * cb_cap + C] = word;
+        return;
     }
+
+    // Rotated IoU.  Phase 1: every (row, column) pair of the tile gets the cheap conservative far-apart test; the pairs
+    // that may overlap are queued in LDS.  Detections are spread over the scene, so typically a few per cent survive,
+    // and phase 2 runs the expensive polygon clipping on a DENSE list (no lane idles while its neighbour clips).
+    // A far pair has overlap exactly 0, hence iou 0: it can only set its bit when thresh < 0, handled by queueing
+    // everything in that case.
+    const int n_r = (n - R * 64) < 64 ? (n - R * 64) : 64, n_c = (n - C * 64) < 64 ? (n - C * 64) : 64;
+    for (int p = tid; p < 64 * 64; p += kBlock) {
+        const int rt = p >> 6, ct = p & 63;
+        if (rt >= n_r || ct >= n_c || (R == C && ct <= rt)) continue;
+        const float ddx = rowrec[rt].cx - colrec[ct].cx, ddy = rowrec[rt].cy - colrec[ct].cy;
+        const float reach = (rowrec[rt].rad + colrec[ct].rad) * 1.0001f + 0.05f;
+        if (thresh >= 0.f && ddx * ddx + ddy * ddy > reach * reach) continue;
+        queue[atomicAdd(&qcount, 1)] = (unsigned short)p;
+    }
+    __syncthreads();
+    const int nq = qcount;
+    for (int q = tid; q < nq; q += kBlock) {
+        const int p = queue[q], rt = p >> 6, ct = p & 63;
+        const PvxBoxRec A = rowrec[rt], B = colrec[ct];
+        const float v = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock));
+        if (v > thresh) atomicOr(&words[rt], 1ull << ct);
+    }
+    __syncthreads();
+    if (tid < n_r) seg_mask[(size_t)(R * 64 + tid) * cb_cap + C] = words[tid];
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -125,33 +125,58 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restri
 }
 
 // Strided conv, phase 1: mark every output cell reached by some (input site, offset).
+// Scattered global atomics run at a few tens of G/s on this chip and serialise when many lanes hit one word, which is
+// exactly what sorted inputs do (x-neighbours share an output word).  So the bits of a workgroup are first merged in a
+// small LDS hash (word -> 64-bit mask, LDS atomics), and each distinct word costs ONE global atomicOr.
+constexpr int kMergeSlots = 1024;
+constexpr unsigned long long kNoWord = ~0ull;
+
 __global__ __launch_bounds__(kBlk) void conv_out_setbits_kernel(const int* __restrict__ coords, int n_in_cap,
                                                                  const int* __restrict__ n_in_dev, ConvGeom g,
                                                                  IndexEntry* out_idx) {
+    __shared__ unsigned long long s_word[kMergeSlots];
+    __shared__ unsigned long long s_bits[kMergeSlots];
+    for (int q = threadIdx.x; q < kMergeSlots; q += kBlk) { s_word[q] = kNoWord; s_bits[q] = 0ull; }
+    __syncthreads();
     const int n_in = live_rows(n_in_cap, n_in_dev);
     const int i = blockIdx.x * kBlk + threadIdx.x;
-    if (i >= n_in) return;
-    const int4 c = reinterpret_cast<const int4*>(coords)[i];
-    if (c.x < 0 || c.x >= g.in.b) return;
-    for (int a = 0; a < g.k[0]; a++) {
-        const int tz = c.y + g.p[0] - a * g.dil[0];
-        if (tz < 0 || tz % g.s[0] != 0) continue;
-        const int oz = tz / g.s[0];
-        if (oz >= g.out.d) continue;
-        for (int bq = 0; bq < g.k[1]; bq++) {
-            const int ty = c.z + g.p[1] - bq * g.dil[1];
-            if (ty < 0 || ty % g.s[1] != 0) continue;
-            const int oy = ty / g.s[1];
-            if (oy >= g.out.h) continue;
-            for (int cq = 0; cq < g.k[2]; cq++) {
-                const int tx = c.w + g.p[2] - cq * g.dil[2];
-                if (tx < 0 || tx % g.s[2] != 0) continue;
-                const int ox = tx / g.s[2];
-                if (ox >= g.out.w) continue;
-                const long long key = lin_key(c.x, oz, oy, ox, g.out);
-                atomicOr(&out_idx[key >> 6].bits, 1ull << (key & 63));
+    if (i < n_in) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        if (c.x >= 0 && c.x < g.in.b) {
+            for (int a = 0; a < g.k[0]; a++) {
+                const int tz = c.y + g.p[0] - a * g.dil[0];
+                if (tz < 0 || tz % g.s[0] != 0) continue;
+                const int oz = tz / g.s[0];
+                if (oz >= g.out.d) continue;
+                for (int bq = 0; bq < g.k[1]; bq++) {
+                    const int ty = c.z + g.p[1] - bq * g.dil[1];
+                    if (ty < 0 || ty % g.s[1] != 0) continue;
+                    const int oy = ty / g.s[1];
+                    if (oy >= g.out.h) continue;
+                    for (int cq = 0; cq < g.k[2]; cq++) {
+                        const int tx = c.w + g.p[2] - cq * g.dil[2];
+                        if (tx < 0 || tx % g.s[2] != 0) continue;
+                        const int ox = tx / g.s[2];
+                        if (ox >= g.out.w) continue;
+                        const long long key = lin_key(c.x, oz, oy, ox, g.out);
+                        const unsigned long long word = (unsigned long long)(key >> 6), bit = 1ull << (key & 63);
+                        unsigned h = (unsigned)((word * 0x9E3779B97F4A7C15ull) >> 54) & (kMergeSlots - 1);
+                        bool merged = false;
+                        for (int probe = 0; probe < 8; probe++) {
+                            const unsigned long long old = atomicCAS(&s_word[h], kNoWord, word);
+                            if (old == kNoWord || old == word) { atomicOr(&s_bits[h], bit); merged = true; break; }
+                            h = (h + 1) & (kMergeSlots - 1);
+                        }
+                        if (!merged) atomicOr(&out_idx[word].bits, bit);   // table crowded: straight to memory
+                    }
+                }
             }
         }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < kMergeSlots; q += kBlk) {
+        const unsigned long long word = s_word[q];
+        if (word != kNoWord) atomicOr(&out_idx[word].bits, s_bits[q]);
     }
 }
 

@@ -567,6 +567,45 @@ __global__ __launch_bounds__(kBlk) void dense_scatter_kernel(const T* __restrict
     out[((size_t)q.x * c + ch) * vol + ((size_t)q.y * h + q.z) * w + q.w] = feat[(size_t)i * c + ch];
 }
 
+// Tiled form (row bytes a multiple of 4): a workgroup takes 64 consecutive rows -- one contiguous chunk of feat, read
+// fully coalesced as 32-bit words -- transposes them through LDS (row stride odd in words: conflict-free column
+// reads), and every wave then writes one channel (pair) at a time with lane = site: rows are in ascending key order,
+// so the 64 stores of an instruction fall on runs of adjacent x of one channel plane.
+constexpr int kDenseWordsMax = 128;   // row words supported by the tiled form (128 channels of fp32, 256 of bf16): 33 KiB of LDS
+
+template <int ESIZE>
+__global__ __launch_bounds__(kBlk) void dense_scatter_tiled_kernel(const unsigned* __restrict__ feat, const int* __restrict__ coords,
+                                                                    int n_cap, const int* __restrict__ n_dev, int c, int batch,
+                                                                    int d, int h, int w, void* __restrict__ out) {
+    extern __shared__ unsigned tile[];
+    const int n = live_rows(n_cap, n_dev);
+    const int row0 = blockIdx.x * 64;
+    if (row0 >= n) return;
+    const int rows = (n - row0) < 64 ? (n - row0) : 64;
+    const int words = c * ESIZE / 4, stride = words | 1;
+    const unsigned* src = feat + (size_t)row0 * words;
+    for (int i = threadIdx.x; i < rows * words; i += kBlk) {
+        const int r = i / words, j = i - r * words;
+        tile[r * stride + j] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane >= rows) return;
+    const int4 q = reinterpret_cast<const int4*>(coords)[row0 + lane];
+    if (q.x < 0 || q.x >= batch || q.y < 0 || q.y >= d || q.z < 0 || q.z >= h || q.w < 0 || q.w >= w) return;
+    const size_t vol = (size_t)d * h * w;
+    const size_t base = (size_t)q.x * c * vol + ((size_t)q.y * h + q.z) * w + q.w;
+    for (int j = wave; j < words; j += kBlk / 64) {
+        const unsigned v = tile[lane * stride + j];
+        if (ESIZE == 4) {
+            ((unsigned*)out)[base + (size_t)j * vol] = v;
+        } else {
+            ((unsigned short*)out)[base + (size_t)(2 * j) * vol] = (unsigned short)(v & 0xffffu);
+            ((unsigned short*)out)[base + (size_t)(2 * j + 1) * vol] = (unsigned short)(v >> 16);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ---------------------------------------------------------------------------------------------------
@@ -780,14 +819,27 @@ extern "C" int pvx_sparse_to_dense(const void* feat, const int* coords, int n, c
     PVX_CHECK_HIP(hipMemsetAsync(out, 0, bytes, st));
     if (n == 0) return PVX_OK;
     if (!feat || !coords) return PVX_ERR_INVALID;
-    const long long total = (long long)n * c;
-    const unsigned grid = (unsigned)PVX_CDIV(total, (long long)kBlk);
-    if (dtype == PVX_F32)
-        hipLaunchKernelGGL(dense_scatter_kernel<float>, dim3(grid), dim3(kBlk), 0, st, (const float*)feat, coords, n, n_dev, c, batch, d, h, w,
-                           (float*)out);
-    else   // 16-bit payloads are moved as raw bits
-        hipLaunchKernelGGL(dense_scatter_kernel<unsigned short>, dim3(grid), dim3(kBlk), 0, st, (const unsigned short*)feat, coords,
-                           n, n_dev, c, batch, d, h, w, (unsigned short*)out);
+    const int esize = (int)elem_size(dtype);
+    const int words = c * esize / 4;
+    if ((c * esize) % 4 == 0 && words <= kDenseWordsMax) {
+        const size_t lds = (size_t)64 * (words | 1) * 4;
+        const unsigned grid = (unsigned)PVX_CDIV(n, 64);
+        if (esize == 4)
+            hipLaunchKernelGGL(dense_scatter_tiled_kernel<4>, dim3(grid), dim3(kBlk), lds, st, (const unsigned*)feat, coords, n, n_dev, c,
+                               batch, d, h, w, out);
+        else
+            hipLaunchKernelGGL(dense_scatter_tiled_kernel<2>, dim3(grid), dim3(kBlk), lds, st, (const unsigned*)feat, coords, n, n_dev, c,
+                               batch, d, h, w, out);
+    } else {
+        const long long total = (long long)n * c;
+        const unsigned grid = (unsigned)PVX_CDIV(total, (long long)kBlk);
+        if (dtype == PVX_F32)
+            hipLaunchKernelGGL(dense_scatter_kernel<float>, dim3(grid), dim3(kBlk), 0, st, (const float*)feat, coords, n, n_dev, c, batch,
+                               d, h, w, (float*)out);
+        else   // 16-bit payloads are moved as raw bits
+            hipLaunchKernelGGL(dense_scatter_kernel<unsigned short>, dim3(grid), dim3(kBlk), 0, st, (const unsigned short*)feat,
+                               coords, n, n_dev, c, batch, d, h, w, (unsigned short*)out);
+    }
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }
