@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=4, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per GPU")
     ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
                     "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")

@@ -626,15 +626,6 @@ template <int CIN, int COUT> long long frag_elems(int K) {
     return (long long)TL::groups(K) * TL::GROUP_U4 * 8;
 }
 
-long long prepared_elems(int cout, int K, int cin, int dtype) {
-    if (mfma_shape(cin, cout, dtype)) {
-#define X(ci, co) if (cin == ci && cout == co) return frag_elems<ci, co>(K);
-        PVX_MFMA_SHAPES(X)
-#undef X
-    }
-    return (long long)cout * K * cin;
-}
-
 int num_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -659,6 +650,29 @@ int ablate_bits() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("PVX_ABLATE"); v = e ? atoi(e) : 0; }
     return v;
+}
+
+// PVX_CONV_IMPL=2 forces the 16x16x32 kernels everywhere; default 3 = 32x32x16 kernels for the shapes they take
+int conv_impl() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PVX_CONV_IMPL"); v = e ? atoi(e) : 3; }
+    return v;
+}
+
+#include "sparse_conv_w32.h"
+
+long long prepared_elems(int cout, int K, int cin, int dtype) {
+    if (w32_shape(cin, cout, K, dtype)) {
+#define X(ci, co) if (cin == ci && cout == co) return frag_elems32<ci, co>(K);
+        PVX_W32_SHAPES(X)
+#undef X
+    }
+    if (mfma_shape(cin, cout, dtype)) {
+#define X(ci, co) if (cin == ci && cout == co) return frag_elems<ci, co>(K);
+        PVX_MFMA_SHAPES(X)
+#undef X
+    }
+    return (long long)cout * K * cin;
 }
 
 template <typename E, int CIN, int COUT>
@@ -753,7 +767,19 @@ extern "C" int pvx_sparse_conv_prepare_weight(const void* weight, int cout, int 
     hipStream_t st = (hipStream_t)stream;
     const long long total = prepared_elems(cout, kvol, cin, dtype);
     const unsigned grid = (unsigned)PVX_CDIV(total, (long long)kBlk);
-    if (mfma_shape(cin, cout, dtype)) {
+    if (w32_shape(cin, cout, kvol, dtype)) {
+#define X(ci, co)                                                                                                          \
+    if (cin == ci && cout == co) {                                                                                         \
+        if (dtype == PVX_BF16)                                                                                             \
+            hipLaunchKernelGGL((weight_swizzle32_kernel<__bf16, ci, co>), dim3(grid), dim3(kBlk), 0, st,                   \
+                               (const __bf16*)weight, kvol, (__bf16*)prepared, total);                                     \
+        else                                                                                                               \
+            hipLaunchKernelGGL((weight_swizzle32_kernel<_Float16, ci, co>), dim3(grid), dim3(kBlk), 0, st,                 \
+                               (const _Float16*)weight, kvol, (_Float16*)prepared, total);                                 \
+    }
+        PVX_W32_SHAPES(X)
+#undef X
+    } else if (mfma_shape(cin, cout, dtype)) {
 #define X(ci, co)                                                                                                          \
     if (cin == ci && cout == co) {                                                                                         \
         if (dtype == PVX_BF16)                                                                                             \
@@ -788,7 +814,19 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
     if (!prepared_weight || !nbr || !out || (n_in > 0 && !feat_in)) return PVX_ERR_INVALID;
     if ((long long)n_out * cout > 0x7fffffff00ll) return PVX_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    if (mfma_shape(cin, cout, dtype)) {
+    if (w32_shape(cin, cout, kvol, dtype)) {
+        int rc32 = PVX_ERR_INVALID;
+#define X(ci, co)                                                                                                             \
+    if (cin == ci && cout == co) {                                                                                            \
+        if (dtype == PVX_BF16)                                                                                                \
+            rc32 = launch_w32<__bf16, ci, co>(feat_in, n_in, prepared_weight, nbr, kvol, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+        else                                                                                                                  \
+            rc32 = launch_w32<_Float16, ci, co>(feat_in, n_in, prepared_weight, nbr, kvol, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+    }
+        PVX_W32_SHAPES(X)
+#undef X
+        if (rc32 != PVX_OK) return rc32;
+    } else if (mfma_shape(cin, cout, dtype)) {
 #define X(ci, co)                                                                                                             \
     if (cin == ci && cout == co) {                                                                                            \
         if (dtype == PVX_BF16)                                                                                                \
