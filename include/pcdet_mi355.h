@@ -122,6 +122,19 @@ int pvx_voxelize_mean_append(const float* points, int n, int c, const float* vsi
                              int row_capacity, int* coords_bzyx, void* mean, int mean_stride, int mean_dtype,
                              int* num_voxels, int* row_end_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* HOST: workspace bytes for pvx_voxelize_mean_batch. */
+size_t pvx_voxelize_batch_workspace_bytes(int frames, int n_points, int max_voxels, int max_points_per_voxel);
+
+/* A whole batch in one launch sequence (8 launches for any number of frames, one frame per blockIdx.y):
+ * points [frames, n, c] (pad short frames with NaN rows: they fall out of range and are dropped); frame f's M_f voxels
+ * land at rows [sum_{g<f} M_g, +M_f) with batch index f, exactly what collate_batch builds on the host
+ * (pcdet/datasets/dataset.py:258-265); num_voxels [frames]; *row_total_dev = min(sum M_f, row_capacity).
+ * Same per-frame first-come semantics and outputs as pvx_voxelize_mean_append. */
+int pvx_voxelize_mean_batch(const float* points, int frames, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                            int max_points_per_voxel, int max_voxels, int row_capacity, int* coords_bzyx, void* mean,
+                            int mean_stride, int mean_dtype, int* num_voxels, int* row_total_dev, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* out[m, c] = voxels[m, T, c].sum(1) / max(num[m], 1).  MeanVFE.forward (mean_vfe.py:26-31) for callers that
  * already hold the padded voxel tensor. */
 int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,

@@ -48,11 +48,17 @@ __device__ __forceinline__ bool cell_of(float p, float lo, float vs, int g, int&
     return true;
 }
 
+// Every kernel below runs one frame per blockIdx.y: frame f uses points + f * n * c, its own hash table
+// (keys / first / vid_of_slot + f * table slots), slot_of_point + f * n, block_sums + f * nb, lists + f * max_voxels * T.
+// The single-frame entry points launch with gridDim.y == 1.
 __global__ __launch_bounds__(kBlk) void vox_insert_kernel(const float* __restrict__ pts, int n, int c, VoxGeom g,
                                                            unsigned long long* keys, int* first, unsigned cap_mask,
                                                            int* __restrict__ slot_of_point) {
     const int i = blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
+    const size_t f = blockIdx.y;
+    pts += f * (size_t)n * c; keys += f * ((size_t)cap_mask + 1); first += f * ((size_t)cap_mask + 1);
+    slot_of_point += f * (size_t)n;
     const float* p = pts + (size_t)i * c;
     int cx, cy, cz;
     if (!(cell_of(p[0], g.x0, g.vx, g.gx, cx) && cell_of(p[1], g.y0, g.vy, g.gy, cy) && cell_of(p[2], g.z0, g.vz, g.gz, cz))) {
@@ -91,9 +97,11 @@ __device__ __forceinline__ int block_rank(bool flag, int* wave_sums, int& block_
 }
 
 __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __restrict__ slot_of_point,
-                                                                    const int* __restrict__ first, int n,
+                                                                    const int* __restrict__ first, int n, size_t table_slots,
                                                                     int* __restrict__ block_sums) {
     __shared__ int wave_sums[kScanBlk / 64];
+    const size_t f = blockIdx.y;
+    slot_of_point += f * (size_t)n; first += f * table_slots; block_sums += f * gridDim.x;
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
     if (i < n) { const int s = slot_of_point[i]; flag = s >= 0 && first[s] == i; }
@@ -102,45 +110,61 @@ __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// exclusive scan of nb block sums in place (one workgroup, chunks of 1024), total -> out_counts
-__global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(int* __restrict__ block_sums, int nb, int max_voxels,
-                                                                    int* __restrict__ num_voxels) {
+// exclusive scan of each frame's nb block sums in place (ONE workgroup walks the frames in order), per-frame voxel
+// count -> num_voxels[f] (clamped to max_voxels).  Batch mode (row_bases != NULL): frame f's rows start at
+// row_bases[f] = sum of the earlier frames' counts and *row_total = min(sum of all, row_capacity).
+__global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(int* __restrict__ block_sums, int nb, int frames, int max_voxels,
+                                                                    int* __restrict__ num_voxels, int* __restrict__ row_bases,
+                                                                    int row_capacity, int* __restrict__ row_total) {
     __shared__ int buf[kScanBlk];
     __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < nb; base += kScanBlk) {
-        const int i = base + threadIdx.x;
-        const int v = i < nb ? block_sums[i] : 0;
-        buf[threadIdx.x] = v;
+    int running = 0;
+    for (int f = 0; f < frames; f++) {
+        int* sums = block_sums + (size_t)f * nb;
+        if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
-        for (int off = 1; off < kScanBlk; off <<= 1) {   // Hillis-Steele inclusive scan in LDS
-            const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+        for (int base = 0; base < nb; base += kScanBlk) {
+            const int i = base + threadIdx.x;
+            const int v = i < nb ? sums[i] : 0;
+            buf[threadIdx.x] = v;
             __syncthreads();
-            buf[threadIdx.x] += t;
+            for (int off = 1; off < kScanBlk; off <<= 1) {   // Hillis-Steele inclusive scan in LDS
+                const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+                __syncthreads();
+                buf[threadIdx.x] += t;
+                __syncthreads();
+            }
+            const int carry = carry_s;
+            if (i < nb) sums[i] = carry + buf[threadIdx.x] - v;
+            __syncthreads();
+            if (threadIdx.x == kScanBlk - 1) carry_s = carry + buf[kScanBlk - 1];
             __syncthreads();
         }
-        const int carry = carry_s;
-        if (i < nb) block_sums[i] = carry + buf[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == kScanBlk - 1) carry_s = carry + buf[kScanBlk - 1];
+        const int total = carry_s < max_voxels ? carry_s : max_voxels;
+        if (threadIdx.x == 0) {
+            num_voxels[f] = total;
+            if (row_bases) row_bases[f] = running;
+        }
+        running += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const int total = carry_s;
-        num_voxels[0] = total < max_voxels ? total : max_voxels;
-    }
+    if (threadIdx.x == 0 && row_total) row_total[0] = running < row_capacity ? running : row_capacity;
 }
 
 __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restrict__ slot_of_point,
                                                                const int* __restrict__ first,
                                                                const unsigned long long* __restrict__ keys, int n,
-                                                               const int* __restrict__ block_offsets, VoxGeom g,
+                                                               size_t table_slots, const int* __restrict__ block_offsets, VoxGeom g,
                                                                int max_voxels, int* __restrict__ vid_of_slot,
                                                                int* __restrict__ coords_zyx, int* __restrict__ coords_bzyx,
                                                                int batch_idx, const int* __restrict__ row_base_dev,
                                                                int row_capacity) {
     __shared__ int wave_sums[kScanBlk / 64];
+    const size_t f = blockIdx.y;
+    slot_of_point += f * (size_t)n; first += f * table_slots; keys += f * table_slots; vid_of_slot += f * table_slots;
+    block_offsets += f * gridDim.x;
+    if (coords_zyx) coords_zyx += f * (size_t)max_voxels * 3;
+    if (gridDim.y > 1) batch_idx = (int)f;
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
     int s = -1;
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
             const int cz = (int)(key / (unsigned long long)g.gy);
             if (coords_zyx) { coords_zyx[rank * 3 + 0] = cz; coords_zyx[rank * 3 + 1] = cy; coords_zyx[rank * 3 + 2] = cx; }
             if (coords_bzyx) {
-                const long long row = (long long)(row_base_dev ? row_base_dev[0] : 0) + rank;
+                const long long row = (long long)(row_base_dev ? row_base_dev[f] : 0) + rank;
                 if (row < row_capacity) reinterpret_cast<int4*>(coords_bzyx)[row] = make_int4(batch_idx, cz, cy, cx);
             }
         }
@@ -164,10 +188,13 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
 }
 
 __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict__ slot_of_point,
-                                                           const int* __restrict__ vid_of_slot, int n, int T,
+                                                           const int* __restrict__ vid_of_slot, int n, size_t table_slots, int T,
                                                            int max_voxels, int* lists, int* __restrict__ point_to_voxel) {
     const int i = blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
+    const size_t f = blockIdx.y;
+    slot_of_point += f * (size_t)n; vid_of_slot += f * table_slots; lists += f * (size_t)max_voxels * T;
+    if (point_to_voxel) point_to_voxel += f * (size_t)n;
     const int s = slot_of_point[i];
     int vid = -1;
     if (s >= 0) { vid = vid_of_slot[s]; if (vid >= max_voxels) vid = -1; }
@@ -185,17 +212,21 @@ __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict_
 }
 
 __global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restrict__ pts, int n, int c, int T,
-                                                           const int* __restrict__ lists,
+                                                           const int* __restrict__ lists, int max_voxels,
                                                            const int* __restrict__ num_voxels,
                                                            float* __restrict__ voxels, int* __restrict__ num_per_voxel,
                                                            void* __restrict__ mean, int mean_stride, int mean_dtype,
                                                            const int* __restrict__ row_base_dev, int row_capacity) {
     // thread = (voxel, output channel); output channels >= c are the zero padding of a widened mean row
     const long long idx = (long long)blockIdx.x * kBlk + threadIdx.x;
-    const int nv = num_voxels[0];
+    const size_t f = blockIdx.y;
+    const int nv = num_voxels[f];
     if (idx >= (long long)nv * mean_stride) return;
+    pts += f * (size_t)n * c; lists += f * (size_t)max_voxels * T;
+    if (voxels) voxels += f * (size_t)max_voxels * T * c;
+    if (num_per_voxel) num_per_voxel += f * (size_t)max_voxels;
     const int v = (int)(idx / mean_stride), ch = (int)(idx % mean_stride);
-    const long long row = (long long)(row_base_dev ? row_base_dev[0] : 0) + v;
+    const long long row = (long long)(row_base_dev ? row_base_dev[f] : 0) + v;
     if (ch >= c) {
         if (mean && row < row_capacity) {
             if (mean_dtype == PVX_F32) ((float*)mean)[row * mean_stride + ch] = 0.f;
@@ -249,26 +280,93 @@ size_t table_capacity(int n) {
 }
 
 struct VoxWorkspace {
-    unsigned long long* keys; int* first; int* vid_of_slot; int* slot_of_point; int* block_sums; int* lists;
+    unsigned long long* keys; int* first; int* lists; int* vid_of_slot; int* slot_of_point; int* block_sums; int* row_bases;
 };
 
+// keys are filled with 0xff, first + lists (adjacent on purpose) with 0x7f: two memsets per call
 template <typename C>
-void carve(C& c, int n, int max_voxels, int T, VoxWorkspace* w) {
-    const size_t cap = table_capacity(n);
-    auto k = c.template take<unsigned long long>(cap);
-    auto f = c.template take<int>(cap);
-    auto vs = c.template take<int>(cap);
-    auto sp = c.template take<int>((size_t)(n > 0 ? n : 1));
-    auto bs = c.template take<int>((size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
-    auto li = c.template take<int>((size_t)max_voxels * T);
-    if (w) { w->keys = (unsigned long long*)k; w->first = (int*)f; w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp;
-             w->block_sums = (int*)bs; w->lists = (int*)li; }
+void carve(C& c, int frames, int n, int max_voxels, int T, VoxWorkspace* w) {
+    const size_t cap = table_capacity(n), F = (size_t)frames;
+    auto k = c.template take<unsigned long long>(F * cap);
+    auto fl = c.template take<int>(F * cap + F * (size_t)max_voxels * T);
+    auto vs = c.template take<int>(F * cap);
+    auto sp = c.template take<int>(F * (size_t)(n > 0 ? n : 1));
+    auto bs = c.template take<int>(F * (size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
+    auto rb = c.template take<int>(F);
+    if (w) { w->keys = (unsigned long long*)k; w->first = (int*)fl; w->lists = fl ? (int*)fl + F * cap : nullptr;
+             w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp; w->block_sums = (int*)bs; w->row_bases = (int*)rb; }
 }
 
 struct SizerShim {   // gives PvxSizer the pointer-returning interface carve() expects
     PvxSizer s;
     template <typename T> T* take(size_t count) { s.take<T>(count); return nullptr; }
 };
+
+struct VoxOut {
+    float* voxels; int* coords_zyx; int* num_points_per_voxel; void* mean; int mean_stride; int mean_dtype;
+    int* point_to_voxel; int* num_voxels; int* coords_bzyx; int batch_idx; const int* row_base_dev; int row_capacity;
+    int* row_end_dev;
+    bool batch;   // frames > 1 semantics: row bases computed here, row_end_dev receives the batch total
+};
+
+int voxelize_impl(const float* points, int frames, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                  int max_points_per_voxel, int max_voxels, const VoxOut& o, void* workspace, size_t workspace_bytes, void* stream) {
+    const int T = max_points_per_voxel;
+    if (frames <= 0 || frames > 65535 || n < 0 || c < 3 || T <= 0 || max_voxels <= 0 || !o.num_voxels || (n > 0 && !points))
+        return PVX_ERR_INVALID;
+    if ((long long)max_voxels * T > 0x7fffffffll) return PVX_ERR_RANGE;
+    int grid[3];
+    int rc = pvx_voxel_grid_size(vsize_xyz, range_xyz, grid);
+    if (rc != PVX_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        PVX_CHECK_HIP(hipMemsetAsync(o.num_voxels, 0, sizeof(int) * frames, st));
+        if (o.row_end_dev) {
+            if (o.batch) { PVX_CHECK_HIP(hipMemsetAsync(o.row_end_dev, 0, sizeof(int), st)); }
+            else {
+                hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, o.num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
+                PVX_CHECK_LAUNCH();
+            }
+        }
+        return PVX_OK;
+    }
+    VoxGeom g = { range_xyz[0], range_xyz[1], range_xyz[2], vsize_xyz[0], vsize_xyz[1], vsize_xyz[2], grid[0], grid[1], grid[2] };
+    PvxCarver cv(workspace, workspace_bytes);
+    VoxWorkspace w;
+    carve(cv, frames, n, max_voxels, T, &w);
+    if (!cv.ok()) return PVX_ERR_WORKSPACE;
+    const size_t cap = table_capacity(n), F = (size_t)frames;
+    PVX_CHECK_HIP(hipMemsetAsync(w.keys, 0xff, F * cap * sizeof(unsigned long long), st));
+    PVX_CHECK_HIP(hipMemsetAsync(w.first, 0x7f, (F * cap + F * (size_t)max_voxels * T) * sizeof(int), st));
+    const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
+    const int* row_bases = o.batch ? w.row_bases : o.row_base_dev;
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, points, n, c, g, w.keys, w.first,
+                       (unsigned)(cap - 1), w.slot_of_point);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, n, cap,
+                       w.block_sums);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, frames, max_voxels, o.num_voxels,
+                       o.batch ? w.row_bases : nullptr, o.row_capacity, o.batch ? o.row_end_dev : nullptr);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, w.keys, n, cap,
+                       w.block_sums, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
+                       o.row_capacity);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,
+                       max_voxels, w.lists, o.point_to_voxel);
+    PVX_CHECK_LAUNCH();
+    const long long work = (long long)max_voxels * o.mean_stride;
+    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk), frames), dim3(kBlk), 0, st, points, n, c, T,
+                       w.lists, max_voxels, o.num_voxels, o.voxels, o.num_points_per_voxel, o.mean, o.mean_stride, o.mean_dtype,
+                       row_bases, o.row_capacity);
+    PVX_CHECK_LAUNCH();
+    if (o.row_end_dev && !o.batch) {
+        hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, o.num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
+        PVX_CHECK_LAUNCH();
+    }
+    return PVX_OK;
+}
 
 }  // namespace
 
@@ -285,72 +383,16 @@ extern "C" int pvx_voxel_grid_size(const float* vsize_xyz, const float* range_xy
 extern "C" size_t pvx_voxelize_hard_workspace_bytes(int n_points, int max_voxels, int max_points_per_voxel) {
     if (n_points < 0 || max_voxels <= 0 || max_points_per_voxel <= 0) return 256;
     SizerShim s;
-    carve(s, n_points, max_voxels, max_points_per_voxel, nullptr);
+    carve(s, 1, n_points, max_voxels, max_points_per_voxel, nullptr);
     return s.s.total();
 }
 
-namespace {
-struct VoxOut {
-    float* voxels; int* coords_zyx; int* num_points_per_voxel; void* mean; int mean_stride; int mean_dtype;
-    int* point_to_voxel; int* num_voxels; int* coords_bzyx; int batch_idx; const int* row_base_dev; int row_capacity;
-    int* row_end_dev;
-};
-
-int voxelize_impl(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz, int max_points_per_voxel,
-                  int max_voxels, const VoxOut& o, void* workspace, size_t workspace_bytes, void* stream) {
-    float* voxels = o.voxels; int* coords_zyx = o.coords_zyx; int* num_points_per_voxel = o.num_points_per_voxel;
-    int* point_to_voxel = o.point_to_voxel; int* num_voxels = o.num_voxels;
-    const int T = max_points_per_voxel;
-    if (n < 0 || c < 3 || T <= 0 || max_voxels <= 0 || !num_voxels || (n > 0 && !points)) return PVX_ERR_INVALID;
-    if ((long long)max_voxels * T > 0x7fffffffll) return PVX_ERR_RANGE;
-    int grid[3];
-    int rc = pvx_voxel_grid_size(vsize_xyz, range_xyz, grid);
-    if (rc != PVX_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) {
-        PVX_CHECK_HIP(hipMemsetAsync(num_voxels, 0, sizeof(int), st));
-        if (o.row_end_dev) {
-            hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
-            PVX_CHECK_LAUNCH();
-        }
-        return PVX_OK;
-    }
-    VoxGeom g = { range_xyz[0], range_xyz[1], range_xyz[2], vsize_xyz[0], vsize_xyz[1], vsize_xyz[2], grid[0], grid[1], grid[2] };
-    PvxCarver cv(workspace, workspace_bytes);
-    VoxWorkspace w;
-    carve(cv, n, max_voxels, T, &w);
-    if (!cv.ok()) return PVX_ERR_WORKSPACE;
-    const size_t cap = table_capacity(n);
-    PVX_CHECK_HIP(hipMemsetAsync(w.keys, 0xff, cap * sizeof(unsigned long long), st));
-    PVX_CHECK_HIP(hipMemsetAsync(w.first, 0x7f, cap * sizeof(int), st));
-    PVX_CHECK_HIP(hipMemsetAsync(w.lists, 0x7f, (size_t)max_voxels * T * sizeof(int), st));
-    const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
-    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts), dim3(kBlk), 0, st, points, n, c, g, w.keys, w.first,
-                       (unsigned)(cap - 1), w.slot_of_point);
-    PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, n, w.block_sums);
-    PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, max_voxels, num_voxels);
-    PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, w.keys, n,
-                       w.block_sums, g, max_voxels, w.vid_of_slot, coords_zyx, o.coords_bzyx, o.batch_idx, o.row_base_dev,
-                       o.row_capacity);
-    PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, T, max_voxels,
-                       w.lists, point_to_voxel);
-    PVX_CHECK_LAUNCH();
-    const long long work = (long long)max_voxels * o.mean_stride;
-    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk)), dim3(kBlk), 0, st, points, n, c, T,
-                       w.lists, num_voxels, voxels, num_points_per_voxel, o.mean, o.mean_stride, o.mean_dtype, o.row_base_dev,
-                       o.row_capacity);
-    PVX_CHECK_LAUNCH();
-    if (o.row_end_dev) {
-        hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
-        PVX_CHECK_LAUNCH();
-    }
-    return PVX_OK;
+extern "C" size_t pvx_voxelize_batch_workspace_bytes(int frames, int n_points, int max_voxels, int max_points_per_voxel) {
+    if (frames <= 0 || n_points < 0 || max_voxels <= 0 || max_points_per_voxel <= 0) return 256;
+    SizerShim s;
+    carve(s, frames, n_points, max_voxels, max_points_per_voxel, nullptr);
+    return s.s.total();
 }
-}  // namespace
 
 extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
                                  int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
@@ -358,8 +400,8 @@ extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float*
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!coords_zyx) return PVX_ERR_INVALID;
     VoxOut o = { voxels, coords_zyx, num_points_per_voxel, mean, c, PVX_F32, point_to_voxel, num_voxels, nullptr, 0, nullptr,
-                 max_voxels, nullptr };
-    return voxelize_impl(points, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
+                 max_voxels, nullptr, false };
+    return voxelize_impl(points, 1, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
 }
 
 extern "C" int pvx_voxelize_mean_append(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
@@ -371,8 +413,20 @@ extern "C" int pvx_voxelize_mean_append(const float* points, int n, int c, const
         batch_idx < 0)
         return PVX_ERR_INVALID;
     VoxOut o = { nullptr, nullptr, nullptr, mean, mean_stride, mean_dtype, nullptr, num_voxels, coords_bzyx, batch_idx,
-                 row_base_dev, row_capacity, row_end_dev };
-    return voxelize_impl(points, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
+                 row_base_dev, row_capacity, row_end_dev, false };
+    return voxelize_impl(points, 1, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
+}
+
+extern "C" int pvx_voxelize_mean_batch(const float* points, int frames, int n, int c, const float* vsize_xyz,
+                                       const float* range_xyz, int max_points_per_voxel, int max_voxels, int row_capacity,
+                                       int* coords_bzyx, void* mean, int mean_stride, int mean_dtype, int* num_voxels,
+                                       int* row_total_dev, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!coords_bzyx || !mean || !row_total_dev || row_capacity <= 0 || mean_stride < c || mean_dtype < 0 || mean_dtype > 2)
+        return PVX_ERR_INVALID;
+    VoxOut o = { nullptr, nullptr, nullptr, mean, mean_stride, mean_dtype, nullptr, num_voxels, coords_bzyx, 0, nullptr,
+                 row_capacity, row_total_dev, true };
+    return voxelize_impl(points, frames, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes,
+                         stream);
 }
 
 extern "C" int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, int max_points_per_voxel, int c,

@@ -167,7 +167,7 @@ class HotPathEngine:
         self.feat0 = torch.zeros((lvl.cap, self.cin0), dtype=self.dtype, device=dev)
         self.points = torch.full((B, self.n_pts_cap, self.C), float('nan'), dtype=torch.float32, device=dev)
         self.num_voxels = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.vox_ws = _lib.workspace(L.pvx_voxelize_hard_workspace_bytes(self.n_pts_cap, self.max_voxels, self.T), dev)
+        self.vox_ws = _lib.workspace(L.pvx_voxelize_batch_workspace_bytes(B, self.n_pts_cap, self.max_voxels, self.T), dev)
 
         self.ops = []          # (name, callable(stream))
         self.conv_records = [] # per conv launch: dict(name, cin, cout, kvol, nbr, level_out) for flop accounting
@@ -275,16 +275,14 @@ class HotPathEngine:
                 self.points[b, n:].fill_(float('nan'))
 
     def voxelize(self, st=None):
+        """all B frames in one launch sequence: voxels of frame b follow those of frame b-1, batch index in column 0"""
         L = self.L
         st = _lib.stream() if st is None else st
         lvl = self.levels[0]
-        lvl.n_dev.zero_()
-        for b in range(self.B):
-            _lib.check(L.pvx_voxelize_mean_append(self.points[b].data_ptr(), self.n_pts_cap, self.C, self.vsize, self.range,
-                                                  self.T, self.max_voxels, b, _lib.ptr(lvl.n_dev), lvl.cap,
-                                                  _lib.ptr(lvl.coords), _lib.ptr(self.feat0), self.cin0, self.code,
-                                                  self.num_voxels[b:b + 1].data_ptr(), _lib.ptr(lvl.n_dev),
-                                                  _lib.ptr(self.vox_ws), self.vox_ws.numel(), st), "pvx_voxelize_mean_append")
+        _lib.check(L.pvx_voxelize_mean_batch(_lib.ptr(self.points), self.B, self.n_pts_cap, self.C, self.vsize, self.range,
+                                             self.T, self.max_voxels, lvl.cap, _lib.ptr(lvl.coords), _lib.ptr(self.feat0),
+                                             self.cin0, self.code, _lib.ptr(self.num_voxels), _lib.ptr(lvl.n_dev),
+                                             _lib.ptr(self.vox_ws), self.vox_ws.numel(), st), "pvx_voxelize_mean_batch")
 
     def backbone(self, st=None, hook=None):
         st = _lib.stream() if st is None else st

@@ -84,3 +84,48 @@ def test_determinism_and_wrappers(cuda_device):
     # stand-alone MeanVFE kernel on the padded tensor
     mv = voxelize.mean_vfe(torch.from_numpy(voxels).to(cuda_device), torch.from_numpy(num).to(cuda_device).float())
     assert np.array_equal(mv.cpu().numpy().view(np.uint32), a["mean"].view(np.uint32))
+
+
+@pytest.mark.parametrize("code,stride", [(0, 5), (2, 16)])
+def test_batch_entry_point(code, stride, cuda_device):
+    """pvx_voxelize_mean_batch: ragged frames (NaN padded, one empty, one hitting the voxel cap) in one launch sequence ==
+    the oracle run frame by frame and concatenated the way collate_batch does (dataset.py:258-265)."""
+    import ctypes
+    from openpcdet_amd import _lib
+    L = _lib.lib()
+    cfg = synth.CONFIGS["kitti_second"]
+    T, cap, c = cfg["T"], 3000, 4
+    sizes = [20000, 0, 7000, 12345, 1]
+    B, n = len(sizes), max(sizes)
+    frames = [synth.config_cloud("kitti_second", 10 + i, n_points=max(s, 1))[:s, :c] for i, s in enumerate(sizes)]
+    pts = np.full((B, n, c), np.nan, np.float32)
+    for b, f in enumerate(frames):
+        pts[b, :len(f)] = f
+    want = [loader.voxelize_hard(f, cfg["voxel"], cfg["range"], T, cap) for f in frames]
+    counts = [len(w[1]) for w in want]
+    assert max(counts) == cap and min(counts) == 0
+    total = sum(counts)
+    dt = torch.float32 if code == 0 else torch.bfloat16
+    for row_cap in (B * cap, total - 100):      # second pass: the batch-level row capacity truncates the last frame
+        d_pts = torch.from_numpy(pts).to(cuda_device)
+        coords = torch.full((row_cap, 4), -7, dtype=torch.int32, device=cuda_device)
+        mean = torch.full((row_cap, stride), 9.0, dtype=dt, device=cuda_device)
+        nv = torch.zeros(B, dtype=torch.int32, device=cuda_device)
+        tot = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+        ws = _lib.workspace(L.pvx_voxelize_batch_workspace_bytes(B, n, cap, T), cuda_device)
+        vs = (ctypes.c_float * 3)(*cfg["voxel"]); rg = (ctypes.c_float * 6)(*cfg["range"])
+        _lib.check(L.pvx_voxelize_mean_batch(_lib.ptr(d_pts), B, n, c, vs, rg, T, cap, row_cap, _lib.ptr(coords), _lib.ptr(mean),
+                                             stride, code, _lib.ptr(nv), _lib.ptr(tot), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                   "pvx_voxelize_mean_batch")
+        torch.cuda.synchronize()
+        assert nv.cpu().tolist() == counts
+        live = min(total, row_cap)
+        assert int(tot.item()) == live
+        w_coords = np.concatenate([np.concatenate([np.full((len(w[1]), 1), b, np.int32), w[1]], 1) for b, w in enumerate(want)])
+        w_mean = np.concatenate([loader.mean_vfe(w[0], w[2]) for w in want])
+        assert np.array_equal(coords[:live].cpu().numpy(), w_coords[:live])
+        assert (coords[live:] == -7).all()
+        got = mean[:live].float().cpu().numpy()
+        ref = torch.from_numpy(w_mean[:live]).to(dt).float().numpy()
+        assert np.array_equal(got[:, :c], ref)
+        assert (got[:, c:] == 0).all() and (mean[live:].float() == 9.0).all()
