@@ -141,6 +141,55 @@ int pvx_mean_vfe(const float* voxels, const int* num_points_per_voxel, int m, in
                  float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Dynamic voxelization + segment reductions (the dynamic VFEs)
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* HOST: bytes of the voxel index / of the workspace pvx_dynamic_voxelize needs for `batch` frames on grid_xyz
+ * (ndim = 3: voxels; ndim = 2: pillars, grid_xyz[2] ignored).  index bytes = 0 if the grid is unsupported. */
+size_t pvx_dynamic_voxelize_index_bytes(int batch, const int* grid_xyz, int ndim);
+size_t pvx_dynamic_voxelize_workspace_bytes(int batch, const int* grid_xyz, int ndim);
+
+/* Dynamic voxelization of a batch: no per-voxel point cap, no voxel cap, voxels sorted ascending by the x-major key
+ * b*gx*gy*gz + x*gy*gz + y*gz + z.  Replaces the floor/mask/merge_coords/torch.unique/decode sequence of
+ * DynamicMeanVFE.forward (pcdet/models/backbones_3d/vfe/dynamic_mean_vfe.py:53-72), DynamicVoxelVFE.forward
+ * (dynamic_voxel_vfe.py:60-71,96-101), DynamicPillarVFE.forward (dynamic_pillar_vfe.py:93-103,132-138; ndim = 2) and
+ * DynamicPillarVFESimple2D.forward (:193-204,231-236).
+ *   points [n, row_floats] f32, columns (batch_idx, x, y, z, ...), row_floats >= 4; (n, n_dev) as for the rulebooks;
+ *   index: pvx_dynamic_voxelize_index_bytes of device memory (left holding the voxel index of the batch);
+ *   point_voxel [n] i32 = unq_inv, -1 for points outside the grid (the reference removes those rows; callers that need
+ *     the compacted form select rows with point_voxel >= 0);
+ *   point_cell [n, 3] i32 = (cx, cy, cz) of each kept point (the reference's points_coords), or NULL;
+ *   voxel_coords_bzyx [voxel_capacity, 4] i32 (z = 0 for pillars), voxel_num_points [voxel_capacity] i32 = unq_cnt (or NULL);
+ *   *num_voxels (device) = number of voxels M; voxels of rank >= voxel_capacity are dropped (their points get -1). */
+int pvx_dynamic_voxelize(const float* points, int n, const int* n_dev, int row_floats, const float* vsize_xyz,
+                         const float* range_xyz, const int* grid_xyz, int ndim, int batch, void* index,
+                         int voxel_capacity, int* point_voxel, int* point_cell, int* voxel_coords_bzyx,
+                         int* voxel_num_points, int* num_voxels, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Per-point input rows of the pillar / voxel feature nets: out[i] = [points[i, 1:] (use_absolute_xyz) or points[i, 4:],
+ * xyz - mean_xyz[voxel], xyz - cell centre, |xyz| (with_distance)], zeros for points with point_voxel < 0.
+ * Replaces dynamic_pillar_vfe.py:106-121 (z_uses_cell = 0: z - z_offset) and dynamic_voxel_vfe.py:74-90
+ * (z_uses_cell = 1).  center_offset_xyz[j] = vsize[j] / 2 + range[j] (HOST arrays, as vsize_xyz).
+ * out_floats must equal the row length this produces. */
+int pvx_dynamic_point_features(const float* points, int n, int row_floats, const int* point_voxel, const int* point_cell,
+                               const float* mean_xyz, const float* vsize_xyz, const float* center_offset_xyz,
+                               int z_uses_cell, int use_absolute_xyz, int with_distance, float* out, int out_floats,
+                               void* stream);
+
+/* scatter_mean(src [n, c], index [n], dim=0) -> out [m, c] = segment sum / max(count, 1); rows with index outside
+ * [0, m) are skipped.  Replaces torch_scatter.scatter_mean (external; call sites dynamic_mean_vfe.py:65,
+ * dynamic_pillar_vfe.py:105, dynamic_voxel_vfe.py:73).  Sums accumulate in binary64 and are rounded once. */
+size_t pvx_scatter_mean_workspace_bytes(int m, int c);
+int pvx_scatter_mean(const float* src, const int* index, int n, const int* n_dev, int c, int m, float* out,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* scatter_max(src [n, c], index [n], dim=0) -> out [m, c] (0 for empty segments), argmax [m, c] i32 or NULL (smallest
+ * source row attaining the maximum; n for empty segments).  Replaces torch_scatter.scatter_max (PFNLayerV2.forward,
+ * dynamic_pillar_vfe.py:40). */
+int pvx_scatter_max(const float* src, const int* index, int n, const int* n_dev, int c, int m, float* out, int* argmax,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * Sparse convolution: site index, rulebook (indice pairs), implicit-GEMM forward, dense()
  *
  * Replaces what the reference gets from the third-party spconv package [spconv] behind

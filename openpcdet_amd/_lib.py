@@ -43,6 +43,15 @@ SIGNATURES = {
     "pvx_voxelize_mean_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                         c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_mean_vfe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "pvx_dynamic_voxelize_index_bytes": (c_size_t, [c_int, c_void_p, c_int]),
+    "pvx_dynamic_voxelize_workspace_bytes": (c_size_t, [c_int, c_void_p, c_int]),
+    "pvx_dynamic_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_dynamic_point_features": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_int, c_void_p, c_int, c_void_p]),
+    "pvx_scatter_mean_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pvx_scatter_mean": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_scatter_max": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

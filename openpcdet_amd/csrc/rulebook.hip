@@ -407,3 +407,5 @@ extern "C" int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd,
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }
+
+#include "dynamic_voxelize.h"
