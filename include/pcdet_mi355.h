@@ -189,6 +189,15 @@ int pvx_scatter_mean(const float* src, const int* index, int n, const int* n_dev
 int pvx_scatter_max(const float* src, const int* index, int n, const int* n_dev, int c, int m, float* out, int* argmax,
                     void* stream);
 
+/* index_add_ along dim 0: out [m, c] (same dtype as src: PVX_F32 / F16 / BF16) = sum of the src rows of each segment, 0
+ * for empty segments.  Replaces features_unique.index_add_(0, _inv, features_cat) in VoxelResBackBone8xVoxelNeXt.bev_out
+ * (pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:155-156).  Segments with one row are copied exactly; shared
+ * segments accumulate in binary64 and round once (the reference rounds to the feature dtype after every addition, in
+ * arrival order). */
+size_t pvx_scatter_sum_workspace_bytes(int m, int c);
+int pvx_scatter_sum(const void* src, int dtype, const int* index, int n, const int* n_dev, int c, int m, void* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Sparse convolution: site index, rulebook (indice pairs), implicit-GEMM forward, dense()
  *
@@ -221,6 +230,15 @@ size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw);
  * Replaces spconv's hash-table build inside get_indice_pairs [spconv]. */
 int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
                          int* perm, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torch.unique(coords, dim=0, return_inverse=True) for coordinate rows: coords_out [out_capacity, 4] = the distinct
+ * rows in ascending (b, z, y, x) order, inverse [n] = row of coords_out each input row maps to (-1 for rows outside the
+ * grid or beyond out_capacity), *n_unique = their number; `index` is left holding the site index of coords_out.
+ * Replaces spconv_backbone_voxelnext.py:154 (bev_out; pass z = 0 and shape {1, H, W} for its (b, y, x) rows).
+ * Workspace: pvx_site_index_workspace_bytes. */
+int pvx_unique_sites(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
+                     int out_capacity, int* coords_out, int* inverse, int* n_unique, void* workspace,
+                     size_t workspace_bytes, void* stream);
 
 /* Submanifold rulebook: nbr[k][o] = row of the site at coords[o] + (k - K/2) * dilation, or -1.  Output rows
  * are the input rows (SubMConv3d, spconv_backbone.py:12,39-46).  ksize odd per axis. */

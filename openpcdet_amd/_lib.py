@@ -52,6 +52,10 @@ SIGNATURES = {
     "pvx_scatter_mean_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pvx_scatter_mean": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_scatter_max": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "pvx_scatter_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pvx_scatter_sum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_unique_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

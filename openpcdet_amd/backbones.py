@@ -150,6 +150,107 @@ class VoxelResBackBone8x(_Backbone8x):
     RES = True
 
 
+def unique_sites_sum(features, indices, spatial_shape, batch_size):
+    """torch.unique(indices, dim=0, return_inverse=True) + zeros.index_add_(0, inverse, features) for coordinate rows
+    (spconv_backbone_voxelnext.py:154-156) -> (unique indices in ascending row order, summed features)."""
+    from . import _lib
+    L = _lib.lib()
+    dev = features.device
+    n, c = features.shape
+    nd = indices.shape[1] - 1
+    assert nd in (2, 3) and indices.dtype == torch.int32
+    shape3 = [1] * (3 - nd) + [int(s) for s in spatial_shape]
+    coords4 = indices if nd == 3 else torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], 1)
+    coords4 = coords4.contiguous()
+    c_shape = _lib.int3(shape3)
+    nbytes = L.pvx_site_index_bytes(batch_size, c_shape)
+    if nbytes == 0:
+        raise ValueError("spatial_shape %s x batch %d is outside what the site index supports" % (spatial_shape, batch_size))
+    feats = features.contiguous()
+    with torch.cuda.device(dev):
+        index = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch_size, c_shape), dev)
+        out4 = torch.empty((max(n, 1), 4), dtype=torch.int32, device=dev)
+        inv = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        num = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.pvx_unique_sites(_lib.ptr(coords4), n, None, batch_size, c_shape, _lib.ptr(index), n, _lib.ptr(out4),
+                                      _lib.ptr(inv), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), "pvx_unique_sites")
+        m = int(num.item())
+        summed = torch.empty((m, c), dtype=feats.dtype, device=dev)
+        ws2 = _lib.workspace(L.pvx_scatter_sum_workspace_bytes(m, c), dev)
+        _lib.check(L.pvx_scatter_sum(_lib.ptr(feats), _lib.DTYPE_CODE[feats.dtype], _lib.ptr(inv), n, None, c, m, _lib.ptr(summed),
+                                     _lib.ptr(ws2), ws2.numel(), _lib.stream()), "pvx_scatter_sum")
+    uniq = out4[:m] if nd == 3 else out4[:m][:, [0, 2, 3]].contiguous()
+    return uniq, summed
+
+
+class VoxelResBackBone8xVoxelNeXt(nn.Module):
+    """Six-stage residual backbone of VoxelNeXt (spconv_backbone_voxelnext.py:69-225): stages conv5 / conv6 keep
+    downsampling, their sites are scaled back onto the stride-8 grid and concatenated with conv4's, the height axis is
+    summed away (bev_out) and two 2-D sparse convs follow.  Same module tree / state_dict names as the reference."""
+
+    def __init__(self, model_cfg=None, input_channels=None, grid_size=None, **kwargs):
+        super().__init__()
+        assert input_channels is not None and grid_size is not None
+        self.model_cfg = model_cfg
+        get = model_cfg.get if model_cfg is not None and hasattr(model_cfg, 'get') else (lambda k, d: d)
+        norm_fn = _norm()
+        ks = get('SPCONV_KERNEL_SIZES', [3, 3, 3, 3])
+        ch = get('CHANNELS', [16, 32, 64, 128, 128])
+        out_channel = get('OUT_CHANNEL', 128)
+        self.sparse_shape = _sparse_shape(grid_size)
+        self.conv_input = spconv.SparseSequential(
+            spconv.SubMConv3d(input_channels, ch[0], 3, padding=1, bias=False, indice_key='subm1'), norm_fn(ch[0]), nn.ReLU())
+        self.conv1 = spconv.SparseSequential(SparseBasicBlock(ch[0], ch[0], norm_fn=norm_fn, indice_key='res1'),
+                                             SparseBasicBlock(ch[0], ch[0], norm_fn=norm_fn, indice_key='res1'))
+        # (stage, in, out, kernel): conv5 and conv6 both use the LAST kernel size (:116,:123)
+        plan = [(2, ch[0], ch[1], ks[0]), (3, ch[1], ch[2], ks[1]), (4, ch[2], ch[3], ks[2]), (5, ch[3], ch[4], ks[3]),
+                (6, ch[4], ch[4], ks[3])]
+        for i, cin, cout, k in plan:
+            setattr(self, 'conv%d' % i, spconv.SparseSequential(
+                post_act_block(cin, cout, k, norm_fn=norm_fn, stride=2, padding=int(k // 2), indice_key='spconv%d' % i,
+                               conv_type='spconv'),
+                SparseBasicBlock(cout, cout, norm_fn=norm_fn, indice_key='res%d' % i),
+                SparseBasicBlock(cout, cout, norm_fn=norm_fn, indice_key='res%d' % i)))
+        self.conv_out = spconv.SparseSequential(
+            spconv.SparseConv2d(ch[3], out_channel, 3, stride=1, padding=1, bias=False, indice_key='spconv_down2'),
+            norm_fn(out_channel), nn.ReLU())
+        self.shared_conv = spconv.SparseSequential(
+            spconv.SubMConv2d(out_channel, out_channel, 3, stride=1, padding=1, bias=True), nn.BatchNorm1d(out_channel),
+            nn.ReLU(True))
+        self.forward_ret_dict = {}
+        self.num_point_features = out_channel
+        self.backbone_channels = {'x_conv1': ch[0], 'x_conv2': ch[1], 'x_conv3': ch[2], 'x_conv4': ch[3]}
+
+    def bev_out(self, x_conv):
+        idx, feats = unique_sites_sum(x_conv.features, x_conv.indices[:, [0, 2, 3]].contiguous(), x_conv.spatial_shape[1:],
+                                      x_conv.batch_size)
+        return spconv.SparseConvTensor(features=feats, indices=idx, spatial_shape=x_conv.spatial_shape[1:],
+                                       batch_size=x_conv.batch_size)
+
+    def forward(self, batch_dict):
+        x = spconv.SparseConvTensor(features=batch_dict['voxel_features'], indices=batch_dict['voxel_coords'].int(),
+                                    spatial_shape=self.sparse_shape, batch_size=batch_dict['batch_size'])
+        x = self.conv_input(x)
+        x_conv1 = self.conv1(x)
+        x_conv2 = self.conv2(x_conv1)
+        x_conv3 = self.conv3(x_conv2)
+        x_conv4 = self.conv4(x_conv3)
+        x_conv5 = self.conv5(x_conv4)
+        x_conv6 = self.conv6(x_conv5)
+        # :194-197 -- the coarser sites land on the stride-8 grid (in place, as the reference does)
+        x_conv5.indices[:, 1:] *= 2
+        x_conv6.indices[:, 1:] *= 4
+        x_conv4 = x_conv4.replace_feature(torch.cat([x_conv4.features, x_conv5.features, x_conv6.features]))
+        x_conv4.indices = torch.cat([x_conv4.indices, x_conv5.indices, x_conv6.indices])
+        out = self.shared_conv(self.conv_out(self.bev_out(x_conv4)))
+        batch_dict.update({'encoded_spconv_tensor': out, 'encoded_spconv_tensor_stride': 8})
+        batch_dict.update({'multi_scale_3d_features': {'x_conv1': x_conv1, 'x_conv2': x_conv2, 'x_conv3': x_conv3,
+                                                       'x_conv4': x_conv4}})
+        batch_dict.update({'multi_scale_3d_strides': {'x_conv1': 1, 'x_conv2': 2, 'x_conv3': 4, 'x_conv4': 8}})
+        return batch_dict
+
+
 class MeanVFE(nn.Module):
     """voxel_features = voxels.sum(1) / clamp_min(voxel_num_points, 1)  (mean_vfe.py:14-33), on pvx_mean_vfe."""
 

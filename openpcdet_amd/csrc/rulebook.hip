@@ -408,4 +408,53 @@ extern "C" int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd,
     return PVX_OK;
 }
 
+
+// ---- unique coordinate rows -----------------------------------------------------------------------------------
+// torch.unique(indices, dim=0, return_inverse=True) for coordinate rows (VoxelResBackBone8xVoxelNeXt.bev_out,
+// spconv_backbone_voxelnext.py:154): the reference sorts the [N, 3] rows lexicographically; the bitmap index gives the
+// same ascending order and the inverse map with no sort.
+namespace {
+
+__global__ __launch_bounds__(kBlk) void unique_inverse_kernel(const int* __restrict__ coords, int n_cap,
+                                                               const int* __restrict__ n_dev, Dims s,
+                                                               const IndexEntry* __restrict__ idx, int out_capacity,
+                                                               int* __restrict__ inverse) {
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= n_cap) return;
+    int r = -1;
+    if (i < live_rows(n_cap, n_dev)) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        if (c.x >= 0 && c.x < s.b && c.y >= 0 && c.y < s.d && c.z >= 0 && c.z < s.h && c.w >= 0 && c.w < s.w) {
+            r = rank_of(idx, lin_key(c.x, c.y, c.z, c.w, s));
+            if (r >= out_capacity) r = -1;
+        }
+    }
+    inverse[i] = r;
+}
+
+}  // namespace
+
+extern "C" int pvx_unique_sites(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
+                                int out_capacity, int* coords_out, int* inverse, int* n_unique, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (n < 0 || out_capacity < 0 || !shape_dhw || !index || !n_unique || (n > 0 && (!coords || !inverse))) return PVX_ERR_INVALID;
+    int rc = pvx_site_index_build(coords, n, n_dev, batch, shape_dhw, index, nullptr, n_unique, workspace, workspace_bytes, stream);
+    if (rc != PVX_OK) return rc;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (coords_out && out_capacity > 0) {
+        hipLaunchKernelGGL(conv_out_coords_kernel, dim3((unsigned)PVX_CDIV(words, (long long)kBlk)), dim3(kBlk), 0, st,
+                           (const IndexEntry*)index, words, s, out_capacity, coords_out);
+        PVX_CHECK_LAUNCH();
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(unique_inverse_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s,
+                           (const IndexEntry*)index, out_capacity, inverse);
+        PVX_CHECK_LAUNCH();
+    }
+    return PVX_OK;
+}
+
 #include "dynamic_voxelize.h"

@@ -87,6 +87,49 @@ __global__ __launch_bounds__(kBlk) void scatter_max_finish_kernel(unsigned* best
     if (arg && !e) arg[t] = live_rows(n_cap, n_dev);
 }
 
+__device__ __forceinline__ float load_as_f32(const void* p, long long i, int dtype) {
+    if (dtype == PVX_F32) return reinterpret_cast<const float*>(p)[i];
+    if (dtype == PVX_F16) return (float)reinterpret_cast<const _Float16*>(p)[i];
+    return (float)reinterpret_cast<const __bf16*>(p)[i];
+}
+__device__ __forceinline__ void store_from_f32(void* p, long long i, int dtype, float v) {
+    if (dtype == PVX_F32) reinterpret_cast<float*>(p)[i] = v;
+    else if (dtype == PVX_F16) reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
+    else reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+}
+
+__global__ __launch_bounds__(kBlk) void scatter_count_kernel(const int* __restrict__ index, int n_cap, const int* __restrict__ n_dev,
+                                                              int m, int* counts) {
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= live_rows(n_cap, n_dev)) return;
+    const int v = index[i];
+    if (v >= 0 && v < m) atomicAdd(&counts[v], 1);
+}
+
+// rows that are alone in their segment are copied; only shared segments pay for atomics
+__global__ __launch_bounds__(kBlk) void scatter_sum_rows_kernel(const void* __restrict__ src, int dtype, const int* __restrict__ index,
+                                                                 int n_cap, const int* __restrict__ n_dev, int c, int m,
+                                                                 const int* __restrict__ counts, double* sums, void* out) {
+    const long long t = (long long)blockIdx.x * kBlk + threadIdx.x;
+    const int n = live_rows(n_cap, n_dev);
+    if (t >= (long long)n * c) return;
+    const int i = (int)(t / c), ch = (int)(t % c);
+    const int v = index[i];
+    if (v < 0 || v >= m) return;
+    const float x = load_as_f32(src, t, dtype);
+    if (counts[v] == 1) store_from_f32(out, (long long)v * c + ch, dtype, x);
+    else unsafeAtomicAdd(&sums[(size_t)v * c + ch], (double)x);
+}
+
+__global__ __launch_bounds__(kBlk) void scatter_sum_finish_kernel(const double* __restrict__ sums, const int* __restrict__ counts,
+                                                                   long long total, int c, int dtype, void* out) {
+    const long long t = (long long)blockIdx.x * kBlk + threadIdx.x;
+    if (t >= total) return;
+    const int k = counts[t / c];
+    if (k == 1) return;
+    store_from_f32(out, t, dtype, k == 0 ? 0.f : (float)sums[t]);
+}
+
 }  // namespace
 
 extern "C" size_t pvx_scatter_mean_workspace_bytes(int m, int c) {
@@ -141,6 +184,33 @@ extern "C" int pvx_scatter_max(const float* src, const int* index, int n, const 
     }
     hipLaunchKernelGGL(scatter_max_finish_kernel, dim3((unsigned)PVX_CDIV(total, (long long)kBlk)), dim3(kBlk), 0, st, best, total,
                        argmax, n, n_dev);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" size_t pvx_scatter_sum_workspace_bytes(int m, int c) { return pvx_scatter_mean_workspace_bytes(m, c); }
+
+extern "C" int pvx_scatter_sum(const void* src, int dtype, const int* index, int n, const int* n_dev, int c, int m, void* out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || c <= 0 || m < 0 || dtype < PVX_F32 || dtype > PVX_BF16) return PVX_ERR_INVALID;
+    if (m == 0) return PVX_OK;
+    if (!out || (n > 0 && (!src || !index))) return PVX_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    PvxCarver cv(workspace, workspace_bytes);
+    double* sums = cv.take<double>((size_t)m * c);
+    int* counts = cv.take<int>((size_t)m);
+    if (!cv.ok()) return PVX_ERR_WORKSPACE;
+    PVX_CHECK_HIP(hipMemsetAsync(sums, 0, (size_t)((char*)(counts + m) - (char*)sums), st));
+    const long long work = (long long)n * c, total = (long long)m * c;
+    if (n > 0) {
+        hipLaunchKernelGGL(scatter_count_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, index, n, n_dev, m, counts);
+        PVX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(scatter_sum_rows_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk)), dim3(kBlk), 0, st, src, dtype,
+                           index, n, n_dev, c, m, counts, sums, out);
+        PVX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(scatter_sum_finish_kernel, dim3((unsigned)PVX_CDIV(total, (long long)kBlk)), dim3(kBlk), 0, st, sums, counts,
+                       total, c, dtype, out);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

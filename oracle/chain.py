@@ -69,6 +69,70 @@ def backbone_chain(net, frames, cfg, timings=None):
     return outs, d
 
 
+def voxelnext_chain(net, x, c, batch):
+    """VoxelResBackBone8xVoxelNeXt.forward (pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:166-225) on the oracle:
+    x [N, C] f32 voxel features, c [N, 4] i32 (b, z, y, x).  -> dict(x_conv1..6 = (coords, feats), x_conv4_cat, bev = (coords [M, 3],
+    feats) after bev_out, out = (coords [M', 3], feats) after conv_out + shared_conv)."""
+    shape = list(net.sparse_shape)
+    books = {}
+    state = {"c": c, "shape": shape}
+
+    def bn(f, m):
+        s, t = _bn_affine(m)
+        return f * s + t
+
+    def conv(f, cv):
+        w = cv.weight.detach().float().cpu().numpy()
+        b = cv.bias.detach().float().cpu().numpy() if cv.bias is not None else None
+        k, s, p = list(cv.kernel_size), list(cv.stride), list(cv.padding)
+        if len(k) == 2:       # 2-D conv = the D = 1, kz = 1 case
+            k, s, p = [1] + k, [1] + s, [0] + p
+            w = w.reshape(w.shape[0], 1, *w.shape[1:])
+        if cv.subm:
+            key = (tuple(state["shape"]), tuple(k))
+            if key not in books:
+                books[key] = loader.subm_rulebook(state["c"], state["shape"], k)
+            nbr = books[key]
+        else:
+            state["c"], nbr, state["shape"] = loader.sparse_rulebook(state["c"], state["shape"], k, s, p)
+        return loader.sparse_conv_fwd(f, w, b, nbr)
+
+    def run(seq_items, x):
+        for it in seq_items:
+            if hasattr(it, "conv1") and hasattr(it, "bn2"):
+                h = np.maximum(bn(conv(x, it.conv1), it.bn1), 0)
+                x = np.maximum(bn(conv(h, it.conv2), it.bn2) + x, 0)
+            else:
+                mods = list(it._modules.values())
+                x = np.maximum(bn(conv(x, mods[0]), mods[1]), 0)
+        return x
+
+    out = {}
+    x = run([net.conv_input], x)
+    for i in range(1, 7):
+        x = run(list(getattr(net, "conv%d" % i)._modules.values()), x)
+        out["x_conv%d" % i] = (state["c"].copy(), x.copy())
+        out["shape%d" % i] = list(state["shape"])
+    c4, c5, c6 = [out["x_conv%d" % i][0].copy() for i in (4, 5, 6)]
+    c5[:, 1:] *= 2
+    c6[:, 1:] *= 4
+    cat_c = np.concatenate([c4, c5, c6])
+    cat_f = np.concatenate([out["x_conv%d" % i][1] for i in (4, 5, 6)])
+    out["x_conv4_cat"] = (cat_c, cat_f)
+    uniq, inv = np.unique(cat_c[:, [0, 2, 3]], axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    bev = np.zeros((uniq.shape[0], cat_f.shape[1]), np.float64)
+    np.add.at(bev, inv, cat_f.astype(np.float64))
+    bev = bev.astype(np.float32)
+    out["bev"] = (uniq.astype(np.int32), bev)
+    state["shape"] = [1] + out["shape4"][1:]
+    state["c"] = np.concatenate([uniq[:, :1], np.zeros_like(uniq[:, :1]), uniq[:, 1:]], 1).astype(np.int32)
+    y = run([net.conv_out], bev)
+    y = run([net.shared_conv], y)
+    out["out"] = (state["c"][:, [0, 2, 3]].copy(), y)
+    return out
+
+
 def heads_nms(boxes, scores, counts, thresh, post_max):
     """boxes [S, cap, >=7], scores [S, cap], counts [S] -> list of kept index arrays (descending score), per segment."""
     out = []
