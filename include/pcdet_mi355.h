@@ -285,6 +285,18 @@ int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prep
                         const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
                         const float* scale, const float* shift, const void* residual, int relu, void* out, void* stream);
 
+/* Backward, weight gradient: grad_weight[co, k, ci] (f32, the module parameter's [cout, kvol, cin] layout) =
+ * sum over live output rows o of grad_out[o, co] * feat_in[nbr[k][o], ci]; feat_in / grad_out are of `dtype`, fp32
+ * accumulation, fixed summation order (partials per site chunk, then one ordered reduction: no float atomics).
+ * Replaces the wgrad of spconv's SparseConvFunction / SubMConvFunction.backward [spconv] (training step, tools/train.py
+ * through every conv of spconv_backbone.py).  The INPUT gradient has no entry point of its own: it is
+ * pvx_sparse_conv_fwd over the inverse rulebook (pvx_inverse_rulebook; for submanifold convs the same rulebook with the
+ * kernel offsets flipped) with the weight transposed to [cin, kvol, cout]. */
+size_t pvx_sparse_conv_wgrad_workspace_bytes(int n_out, int kvol, int cin, int cout);
+int pvx_sparse_conv_wgrad(const void* feat_in, int n_in, int cin, const void* grad_out, const int* nbr, int kvol, int n_out,
+                          const int* n_out_dev, int cout, int dtype, float* grad_weight, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* SparseConvTensor.dense() (pcdet/models/backbones_2d/map_to_bev/height_compression.py:22): zero-fill
  * out [batch, c, D, H, W] and scatter the rows, writing the channel-major layout directly. */
 int pvx_sparse_to_dense(const void* feat, const int* coords, int n, const int* n_dev, int c, int dtype, int batch,

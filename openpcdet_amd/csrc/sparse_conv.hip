@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kBlk) void dense_scatter_tiled_kernel(const unsigne
 // ---------------------------------------------------------------------------------------------------
 inline size_t elem_size(int dtype) { return dtype == PVX_F32 ? 4 : 2; }
 
-#define PVX_MFMA_SHAPES(X) X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 128) X(128, 128) X(128, 256) X(256, 256)
+#define PVX_MFMA_SHAPES(X) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(128, 256) X(256, 256)
 
 bool mfma_shape(int cin, int cout, int dtype) {
     if (dtype == PVX_F32) return false;

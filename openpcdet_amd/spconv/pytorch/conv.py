@@ -30,17 +30,33 @@ def _to3(v, ndim, fill):
 
 
 class _SparseConvFunction(torch.autograd.Function):
-    """Forward on the HIP implicit-GEMM kernel.  Backward (dgrad through the inverse rulebook + wgrad) is row f of
-    DESIGN.md's scope table and not built yet: asking for gradients raises instead of silently detaching."""
+    """Forward on the HIP implicit-GEMM kernel; backward = the same kernel over the inverse rulebook with the weight
+    transposed (input gradient) + pvx_sparse_conv_wgrad (weight gradient) + a column sum (bias gradient).
+    `back` = (callable returning the rulebook [K, n_in] that maps input rows to output rows, flip): for a submanifold conv
+    the forward rulebook itself serves, read with the kernel offsets reversed (coords[o] = coords[i] + off(k) <=>
+    coords[i] = coords[o] + off(K-1-k)), so nothing extra is built."""
 
     @staticmethod
-    def forward(ctx, features, weight, bias, module, nbr, n_out):
+    def forward(ctx, features, weight, bias, module, nbr, n_out, back):
+        ctx.module, ctx.nbr, ctx.n_out, ctx.back = module, nbr, n_out, back
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(features, weight)
         return module._launch(features, weight, bias, nbr, n_out)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError("sparse convolution backward is not implemented in this build (forward / inference "
-                                  "path only); run under torch.no_grad()")
+        features, weight = ctx.saved_tensors
+        module = ctx.module
+        g = grad_out.to(features.dtype).contiguous()
+        grad_feat = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            nbr_back, flip = ctx.back
+            grad_feat = module._dgrad(g, weight, nbr_back(), flip, features.shape[0])
+        if ctx.needs_input_grad[1]:
+            grad_w = module._wgrad(features, g, ctx.nbr, ctx.n_out).view_as(weight).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = g.float().sum(0).to(module.bias.dtype)
+        return grad_feat, grad_w, grad_b, None, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -123,6 +139,40 @@ class SparseConvolution(SparseModule):
                        "pvx_sparse_conv_fwd")
         return out
 
+    # ---- backward ------------------------------------------------------------------------------------------
+    def _dgrad(self, grad_out, weight, nbr_back, flip, n_in):
+        """grad_in[i] = sum_k W[:, k, :]^T grad_out[o(k, i)]: a forward conv Cout -> Cin over the inverse rulebook"""
+        L = _lib.lib()
+        dev, dtype = grad_out.device, grad_out.dtype
+        kvol = int(np.prod(self.kernel_size))
+        w = weight.detach().reshape(self.out_channels, kvol, self.in_channels)
+        if flip:
+            w = w.flip(1)
+        w = w.permute(2, 1, 0).to(dtype).contiguous()            # [Cin, K, Cout]
+        code = _lib.DTYPE_CODE[dtype]
+        pw = torch.empty(L.pvx_sparse_conv_weight_bytes(self.in_channels, kvol, self.out_channels, code), dtype=torch.uint8, device=dev)
+        out = torch.empty((n_in, self.in_channels), dtype=dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), self.in_channels, kvol, self.out_channels, code, _lib.ptr(pw),
+                                                        _lib.stream()), "pvx_sparse_conv_prepare_weight")
+            _lib.check(L.pvx_sparse_conv_fwd(_lib.ptr(grad_out), grad_out.shape[0], self.out_channels, _lib.ptr(pw), None,
+                                             _lib.ptr(nbr_back), kvol, n_in, None, self.in_channels, code, None, None, None, 0,
+                                             _lib.ptr(out), _lib.stream()), "pvx_sparse_conv_fwd (dgrad)")
+        return out
+
+    def _wgrad(self, features, grad_out, nbr, n_out):
+        L = _lib.lib()
+        dev = features.device
+        kvol = int(np.prod(self.kernel_size))
+        gw = torch.empty((self.out_channels, kvol, self.in_channels), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(L.pvx_sparse_conv_wgrad_workspace_bytes(n_out, kvol, self.in_channels, self.out_channels), dev)
+            _lib.check(L.pvx_sparse_conv_wgrad(_lib.ptr(features), features.shape[0], self.in_channels, _lib.ptr(grad_out),
+                                               _lib.ptr(nbr), kvol, n_out, None, self.out_channels,
+                                               _lib.DTYPE_CODE[features.dtype], _lib.ptr(gw), _lib.ptr(ws), ws.numel(),
+                                               _lib.stream()), "pvx_sparse_conv_wgrad")
+        return gw
+
     # ---- rulebooks ---------------------------------------------------------------------------------------------
     def _build_subm(self, x):
         L = _lib.lib()
@@ -196,7 +246,7 @@ class SparseConvolution(SparseModule):
             raise RuntimeError("sparse convolution runs on the GPU only (there is no CPU fallback)")
         assert feats.shape[1] == self.in_channels, "channel mismatch: %d vs %d" % (feats.shape[1], self.in_channels)
         if torch.is_autocast_enabled():
-            feats = feats.to(torch.get_autocast_gpu_dtype())
+            feats = feats.to(torch.get_autocast_dtype('cuda'))
         if feats.dtype not in _lib.DTYPE_CODE:
             raise TypeError("unsupported feature dtype %s" % feats.dtype)
         feats = feats.contiguous()
@@ -209,6 +259,7 @@ class SparseConvolution(SparseModule):
             nbr, n_out = self._inverse_of(input, data), data.n_in
             out_indices, out_shape = data.in_indices, data.in_spatial_shape
             seed = None
+            back = (lambda d=data: d.nbr, False)
         elif self.subm:
             if self.conv1x1 and data is None:
                 data = "identity"
@@ -226,6 +277,7 @@ class SparseConvolution(SparseModule):
                 nbr, n_out = data.nbr, data.n_out
             out_indices, out_shape = input.indices, input.spatial_shape
             seed = None
+            back = (lambda n=nbr: n, True)
         else:
             if data is None:
                 data = self._build_strided(input)
@@ -236,10 +288,11 @@ class SparseConvolution(SparseModule):
             nbr, n_out = data.nbr, data.n_out
             out_indices, out_shape = data.out_indices, data.out_spatial_shape
             seed = data.out_index_cache
+            back = (lambda d=data, x=input: self._inverse_of(x, d), False)
 
         needs_grad = torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad)
         if needs_grad:
-            out_feats = _SparseConvFunction.apply(feats, self.weight, self.bias, self, nbr, n_out)
+            out_feats = _SparseConvFunction.apply(feats, self.weight, self.bias, self, nbr, n_out, back)
         else:
             out_feats = self._launch(feats, self.weight, self.bias, nbr, n_out)
 

@@ -1,0 +1,237 @@
+"""GPU parity of the sparse-conv BACKWARD (BASELINE.json configs[3], the training step): gradients from the HIP path
+(dgrad = implicit GEMM over the inverse rulebook, wgrad = pvx_sparse_conv_wgrad, through the module API's autograd) against
+torch autograd on the CPU over the ORACLE's rulebooks, where a sparse conv is written as the reference's "native"
+gather -> GEMM -> scatter-add per kernel offset.  Bar (north_star): rel-L2 <= 1e-3 fp32, <= 1e-2 bf16 / fp16."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import loader
+from openpcdet_amd import backbones, synth, voxelize
+from openpcdet_amd.spconv import pytorch as spconv
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 1e-2}
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def ref_conv(feat, weight, bias, nbr):
+    """feat [n_in, cin], weight [cout, K, cin], nbr [K, n_out] (numpy, -1 = no pair) -> [n_out, cout]; differentiable"""
+    pad = torch.cat([feat, feat.new_zeros(1, feat.shape[1])])          # index -1 picks the zero row
+    idx = torch.from_numpy(np.asarray(nbr, np.int64)).to(feat.device)
+    out = None
+    for k in range(idx.shape[0]):
+        term = pad[idx[k]] @ weight[:, k, :].t()
+        out = term if out is None else out + term
+    return out if bias is None else out + bias
+
+
+def random_sites(n, batch, shape, seed):
+    r = np.random.default_rng(seed)
+    cells = r.choice(batch * int(np.prod(shape)), n, replace=False)
+    c = np.stack(np.unravel_index(cells, [batch] + list(shape)), 1).astype(np.int32)
+    return c[r.permutation(n)]
+
+
+def _grads(layer, x_feat, coords, shape, batch, dtype, up, dev):
+    f = torch.from_numpy(x_feat).to(dev).to(dtype).requires_grad_(True)
+    x = spconv.SparseConvTensor(f, torch.from_numpy(coords).to(dev), shape, batch)
+    layer = layer.to(dev).to(dtype)
+    for p in layer.parameters():
+        p.grad = None
+    y = layer(x)
+    (y.features.float() * torch.from_numpy(up).to(dev)).sum().backward()
+    out = dict(x=f.grad.float().cpu().numpy(), w=layer.weight.grad.float().cpu().numpy())
+    if layer.bias is not None:
+        out["b"] = layer.bias.grad.float().cpu().numpy()
+    layer.float()
+    return y, out
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (5, 16), (48, 24)])
+def test_subm_and_strided_grads(cin, cout, dtype, cuda_device):
+    torch.manual_seed(cin * 1000 + cout)
+    shape, batch, n = [9, 40, 40], 2, 6000
+    coords = random_sites(n, batch, shape, cin + cout)
+    r = np.random.default_rng(1)
+    x = r.normal(size=(n, cin)).astype(np.float32)
+    if dtype != torch.float32:      # what the device sees
+        x = torch.from_numpy(x).to(dtype).float().numpy()
+    for kind in ("subm", "strided"):
+        if kind == "subm":
+            layer = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=True, indice_key="s")
+            nbr = loader.subm_rulebook(coords, shape, [3, 3, 3])
+            n_out = n
+        else:
+            layer = spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=False, indice_key="d")
+            _, nbr, _ = loader.sparse_rulebook(coords, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+            n_out = nbr.shape[1]
+        up = r.normal(size=(n_out, cout)).astype(np.float32)
+        y, got = _grads(layer, x, coords, shape, batch, dtype, up, cuda_device)
+        assert y.features.shape == (n_out, cout)
+        w = layer.weight.detach().cpu().to(dtype).float().reshape(cout, 27, cin).requires_grad_(True)
+        b = layer.bias.detach().cpu().float().requires_grad_(True) if layer.bias is not None else None
+        xf = torch.from_numpy(x).requires_grad_(True)
+        ref = ref_conv(xf, w, b, nbr)
+        if dtype != torch.float32:      # the upstream gradient reaches the kernels rounded to the feature dtype
+            up = torch.from_numpy(up).to(dtype).float().numpy()
+        (ref * torch.from_numpy(up)).sum().backward()
+        tol = TOL[dtype]
+        assert rel_l2(got["x"], xf.grad.numpy()) <= tol, (kind, "dgrad")
+        assert rel_l2(got["w"].reshape(cout, 27, cin), w.grad.numpy()) <= tol, (kind, "wgrad")
+        if b is not None:
+            assert rel_l2(got["b"], b.grad.numpy()) <= tol, (kind, "bias")
+
+
+def test_inverse_conv_and_2d_grads(cuda_device):
+    torch.manual_seed(3)
+    shape, batch, n, c = [8, 30, 30], 2, 4000, 32
+    coords = random_sites(n, batch, shape, 5)
+    r = np.random.default_rng(2)
+    x = r.normal(size=(n, c)).astype(np.float32)
+    down = spconv.SparseConv3d(c, 64, 3, stride=2, padding=1, bias=False, indice_key="d1").to(cuda_device)
+    upc = spconv.SparseInverseConv3d(64, c, 3, indice_key="d1", bias=True).to(cuda_device)
+    f = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
+    y = upc(down(spconv.SparseConvTensor(f, torch.from_numpy(coords).to(cuda_device), shape, batch)))
+    g = r.normal(size=(n, c)).astype(np.float32)
+    (y.features * torch.from_numpy(g).to(cuda_device)).sum().backward()
+    _, nbr, _ = loader.sparse_rulebook(coords, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    inv = loader.inverse_rulebook(nbr, n)
+    xf = torch.from_numpy(x).requires_grad_(True)
+    w1 = down.weight.detach().cpu().reshape(64, 27, c).requires_grad_(True)
+    w2 = upc.weight.detach().cpu().reshape(c, 27, 64).requires_grad_(True)
+    b2 = upc.bias.detach().cpu().requires_grad_(True)
+    ref = ref_conv(ref_conv(xf, w1, None, nbr), w2, b2, inv)
+    (ref * torch.from_numpy(g)).sum().backward()
+    assert rel_l2(y.features.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-4
+    assert rel_l2(f.grad.cpu().numpy(), xf.grad.numpy()) <= 1e-3
+    assert rel_l2(down.weight.grad.cpu().numpy().reshape(64, 27, c), w1.grad.numpy()) <= 1e-3
+    assert rel_l2(upc.weight.grad.cpu().numpy().reshape(c, 27, 64), w2.grad.numpy()) <= 1e-3
+    assert rel_l2(upc.bias.grad.cpu().numpy(), b2.grad.numpy()) <= 1e-3
+    # 2-D: SubMConv2d on (b, y, x) rows
+    c2 = np.unique(coords[:, [0, 2, 3]], axis=0).astype(np.int32)
+    x2 = r.normal(size=(len(c2), 16)).astype(np.float32)
+    conv2 = spconv.SubMConv2d(16, 32, 3, padding=1, bias=True).to(cuda_device)
+    f2 = torch.from_numpy(x2).to(cuda_device).requires_grad_(True)
+    y2 = conv2(spconv.SparseConvTensor(f2, torch.from_numpy(c2).to(cuda_device), shape[1:], batch))
+    y2.features.square().sum().backward()
+    c4 = np.concatenate([c2[:, :1], np.zeros_like(c2[:, :1]), c2[:, 1:]], 1)
+    nbr2 = loader.subm_rulebook(c4, [1] + shape[1:], [1, 3, 3])
+    xf2 = torch.from_numpy(x2).requires_grad_(True)
+    w = conv2.weight.detach().cpu().reshape(32, 9, 16).requires_grad_(True)
+    ref_conv(xf2, w, conv2.bias.detach().cpu(), nbr2).square().sum().backward()
+    assert rel_l2(f2.grad.cpu().numpy(), xf2.grad.numpy()) <= 1e-3
+    assert rel_l2(conv2.weight.grad.cpu().numpy().reshape(32, 9, 16), w.grad.numpy()) <= 1e-3
+
+
+def _ref_backbone_loss(net, x, coords, shape, batch, up):
+    """VoxelResBackBone8x in TRAINING mode re-evaluated by torch on the CPU over oracle rulebooks; returns the scalar loss
+    whose .backward() fills net_cpu's parameter grads (BatchNorm uses batch statistics, as in a training step)."""
+    state = {"c": coords, "shape": list(shape)}
+    books = {}
+
+    def conv(f, cv):
+        kvol = int(np.prod(cv.kernel_size))
+        w = cv.weight.reshape(cv.out_channels, kvol, cv.in_channels)
+        if cv.subm:
+            key = tuple(state["shape"])
+            if key not in books:
+                books[key] = loader.subm_rulebook(state["c"], state["shape"], cv.kernel_size)
+            nbr = books[key]
+        else:
+            state["c"], nbr, state["shape"] = loader.sparse_rulebook(state["c"], state["shape"], cv.kernel_size, cv.stride, cv.padding)
+        return ref_conv(f, w, cv.bias, nbr)
+
+    def bn(f, m):
+        return F.batch_norm(f, None, None, m.weight, m.bias, True, 0.0, m.eps)
+
+    seqs = [net.conv_input] + [getattr(net, n) for n in ("conv1", "conv2", "conv3", "conv4")] + [net.conv_out]
+    for si, seq in enumerate(seqs):
+        for it in ([seq] if si in (0, 5) else list(seq._modules.values())):
+            if hasattr(it, "conv1") and hasattr(it, "bn2"):
+                h = torch.relu(bn(conv(x, it.conv1), it.bn1))
+                x = torch.relu(bn(conv(h, it.conv2), it.bn2) + x)
+            else:
+                mods = list(it._modules.values())
+                x = torch.relu(bn(conv(x, mods[0]), mods[1]))
+    return (x * up).sum(), x
+
+
+def test_training_step_backbone_grads(cuda_device):
+    """one fp32 training step of VoxelResBackBone8x on a Waymo-range frame pair: every parameter gradient vs the CPU autograd
+    reference; then the same step under bf16 autocast against the fp32 gradients"""
+    cfg = synth.CONFIGS["waymo_centerpoint"]
+    torch.manual_seed(31)
+    grid = loader.voxel_grid_size(cfg["voxel"], cfg["range"])
+    net = backbones.VoxelResBackBone8x(input_channels=cfg["C"], grid_size=np.array(grid)).train()
+    feats, coords = [], []
+    for b, s in enumerate((41, 42)):
+        pts = synth.config_cloud("waymo_centerpoint", s, n_points=12000)
+        vox, czyx, num, _ = loader.voxelize_hard(pts, cfg["voxel"], cfg["range"], cfg["T"], cfg["max_voxels"])
+        feats.append(loader.mean_vfe(vox, num))
+        coords.append(np.concatenate([np.full((len(czyx), 1), b, np.int32), czyx], 1))
+    x, c = np.concatenate(feats), np.concatenate(coords)
+    xr = torch.from_numpy(x)
+    # reference first (CPU, fp32)
+    n_out = None
+    loss_ref, out_ref = _ref_backbone_loss(net, xr, c, net.sparse_shape, 2, 1.0)
+    up = torch.from_numpy(np.random.default_rng(3).normal(size=tuple(out_ref.shape)).astype(np.float32))
+    for p in net.parameters():
+        p.grad = None
+    loss_ref, out_ref = _ref_backbone_loss(net, xr, c, net.sparse_shape, 2, up)
+    loss_ref.backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    # device
+    net = net.to(cuda_device)
+    bd = net({"voxel_features": xr.to(cuda_device), "voxel_coords": torch.from_numpy(c).to(cuda_device), "batch_size": 2})
+    out = bd["encoded_spconv_tensor"]
+    assert rel_l2(out.features.detach().cpu().numpy(), out_ref.detach().numpy()) <= 1e-3
+    (out.features * up.to(cuda_device)).sum().backward()
+    got32 = {k: p.grad.detach().cpu() for k, p in net.named_parameters()}
+    assert set(got32) == set(want)
+    def after_bn(k):   # a conv bias followed by batch-statistic BatchNorm has an analytically ZERO gradient: both sides hold
+        return k.endswith(("conv1.bias", "conv2.bias"))        # rounding noise only, which is checked to be just that
+    for k in want:
+        if after_bn(k):
+            assert got32[k].abs().max() <= 1e-2 and want[k].abs().max() <= 1e-2, k
+        else:
+            assert rel_l2(got32[k].numpy(), want[k].numpy()) <= 2e-3, k
+    # bf16 autocast step: same loss, gradients land in fp32 parameters
+    for p in net.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        bd = net({"voxel_features": xr.to(cuda_device), "voxel_coords": torch.from_numpy(c).to(cuda_device), "batch_size": 2})
+        out16 = bd["encoded_spconv_tensor"].features
+    assert net.conv_input[0].weight.dtype == torch.float32
+    (out16.float() * up.to(cuda_device)).sum().backward()
+    worst, errs = 0.0, {}
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32, k
+        if not after_bn(k):
+            errs[k] = rel_l2(p.grad.cpu().numpy(), want[k].numpy())
+            worst = max(worst, errs[k])
+    # 21 bf16 layers deep with batch-statistic BatchNorm in between, the per-layer 1e-2 bar compounds (BatchNorm's backward
+    # subtracts the batch-correlated part of the gradient, which amplifies rounding).  The yardstick is torch itself: the same
+    # network with every conv written as gather -> torch.matmul -> add, run under the same bf16 autocast on the device.
+    for p in net.parameters():
+        p.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss_t, _ = _ref_backbone_loss(net, xr.to(cuda_device), c, net.sparse_shape, 2, up.to(cuda_device))
+    loss_t.backward()
+    worst_torch = max(rel_l2(p.grad.cpu().numpy(), want[k].numpy()) for k, p in net.named_parameters() if not after_bn(k))
+    print("bf16 autocast: worst gradient error ours %.4f, torch gather-GEMM-scatter %.4f" % (worst, worst_torch))
+    assert worst <= max(6e-2, 1.25 * worst_torch), (worst, worst_torch, sorted(errs.items(), key=lambda kv: -kv[1])[:8])
+    # and an optimizer step moves the weights
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    before = net.conv_input[0].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, net.conv_input[0].weight.detach())
