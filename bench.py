@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from openpcdet_amd import _lib, backbones, engine, synth  # noqa: E402
+from openpcdet_amd import dist as pdist  # noqa: E402
 
 WORKLOAD = "nuscenes_centerpoint"
 HEADS, BOXES_PER_HEAD, NMS_THRESH, NMS_POST = 6, 500, 0.2, 83   # cbgs_voxel0075_res3d_centerpoint.yaml:89-132
@@ -94,17 +95,13 @@ def main():
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm; used for the timing bracket only
+    rank, world = pdist.init_from_env(dev)   # RCCL ("nccl") when launched by torchrun; used for the timing bracket only
+    dist = torch.distributed if world > 1 else None
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     cfg = synth.CONFIGS[WORKLOAD]
@@ -171,23 +168,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # barrier + device sync on both sides, MAX over ranks (openpcdet_amd/dist.py; tests/test_dist_gloo.py runs it at world 2)
+    elapsed = pdist.timed_steps(step, args.steps, device=dev, first=args.warmup)
     note("timed region done: %.3f s" % elapsed)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     assert not eng.overflowed(), "a level overflowed its row capacity"
     rows = eng.level_rows()
 
@@ -232,10 +215,10 @@ def main():
         achieved = flops / (conv_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": None,
-                    "kernel": "sparse_conv_mfma_kernel (%d launches/step)" % conv_launches,
+                    "kernel": "sparse_conv_w32_kernel + sparse_conv_mfma2_kernel (%d conv launches/step)" % conv_launches,
                     "flops_per_step": flops, "ms_per_step": round(conv_ms, 4)}
         cpu = None
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:     # reported at N = 1 only
             v, threads, sample = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(),
                                               counts.cpu().numpy())
             cpu = {"value": round(v, 4), "unit": "frames/s", "cores": threads, "kind": "port", "sample": sample}
