@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                 const int i = q * NT + tid;
                 const int k = i / TM, site = tile0 + (i - k * TM);
                 int v = -1;
-                if (k < K && site < n_live && !(dbg & 16)) v = nbr[(size_t)k * n_out + site];
+                if (k < K && site < n_live && !(dbg & 16)) v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + site);   // streamed once: keep L2 for the gathered rows
                 tmp[q] = v;
             }
             uint4 wtmp[RESIDENT ? 1 : PL::WREG];
@@ -281,8 +281,8 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                     }
                 }
                 if (residual) {
-                    const uint4 r0 = *reinterpret_cast<const uint4*>(residual + base);
-                    const uint4 r1 = *reinterpret_cast<const uint4*>(residual + base + 8);
+                    const u32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base));
+                    const u32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base + 8));
                     E re[16];
                     __builtin_memcpy(re, &r0, 16);
                     __builtin_memcpy(re + 8, &r1, 16);
@@ -292,11 +292,11 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                 E oe[16];
 #pragma unroll
                 for (int q = 0; q < 16; q++) oe[q] = (E)(relu ? fmaxf(v[q], 0.f) : v[q]);
-                uint4 o0, o1;
+                u32x4 o0, o1;
                 __builtin_memcpy(&o0, oe, 16);
                 __builtin_memcpy(&o1, oe + 8, 16);
-                *reinterpret_cast<uint4*>(out + base) = o0;
-                *reinterpret_cast<uint4*>(out + base + 8) = o1;
+                __builtin_nontemporal_store(o0, reinterpret_cast<u32x4*>(out + base));
+                __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(out + base + 8));
             }
         }
     }
@@ -345,6 +345,9 @@ int launch_w32(const void* feat, int n_in, const void* w, const int* nbr, int K,
     }
     {
         // MFMA-bound layers: 8 waves x 32 sites, weights streamed in 32-KiB chunks shared by the 8 waves
+        // MFMA-heavy layers: 8 waves x 32 sites, weights streamed in 32-KiB chunks shared by the 8 waves.  Measured alternatives
+        // (profiles/r01_d_conv_variants.txt): two subtiles per wave (half the weight traffic per site) -- no change; 4-wave
+        // workgroups with a 12-deep gather ring -- 2.1x slower (one wave per SIMD cannot cover the MFMA dependency chains).
         constexpr int MT = 1, TM = (NT / 64) * 32 * MT;
         constexpr int D = CIN >= 128 ? 2 : 4;
         int grid = num_cus();
