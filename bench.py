@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per GPU")
     ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
                     "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")
+    ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the conv stream (A/B switch)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one plan: geometry overlaps only the convs of its own batch")
+    ap.add_argument("--no-overlap", action="store_true", help="one stream: no geometry / conv / NMS overlap (A/B switch)")
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
@@ -110,19 +113,32 @@ def main():
     eng = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
                                dtype=torch.bfloat16, device=dev, level_capacity_factor=2.0)
     nms = engine.BatchedNMS(B * HEADS, BOXES_PER_HEAD, NMS_THRESH, NMS_POST, device=dev)
+    pipelined = not (args.no_overlap or args.graph or args.no_pipeline)
+    eng2 = None
+    if pipelined:   # two plans alternate so that the geometry of batch i+1 runs beside the convolutions of batch i
+        eng2 = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
+                                    dtype=torch.bfloat16, device=dev, level_capacity_factor=2.0)
     frames, boxes, scores, counts = make_inputs(cfg, rank, P, dev)
     # static NMS inputs of one step (what the dense head would have decoded for the B frames)
     s_boxes = torch.zeros((B * HEADS, BOXES_PER_HEAD, 9), device=dev)
     s_scores = torch.zeros((B * HEADS, BOXES_PER_HEAD), device=dev)
     s_counts = torch.zeros((B * HEADS,), dtype=torch.int32, device=dev)
 
-    def load(step):
+    def load_points(step, plan=None):
+        plan = eng if plan is None else plan
+        for b in range(B):
+            plan.points[b].copy_(frames[(step * B + b) % P])
+
+    def load_boxes(step):
         for b in range(B):
             i = (step * B + b) % P
-            eng.points[b].copy_(frames[i])
             s_boxes[b * HEADS:(b + 1) * HEADS].copy_(boxes[i])
             s_scores[b * HEADS:(b + 1) * HEADS].copy_(scores[i])
             s_counts[b * HEADS:(b + 1) * HEADS].copy_(counts[i])
+
+    def load(step):
+        load_points(step)
+        load_boxes(step)
 
     result = {}
 
@@ -130,9 +146,20 @@ def main():
         if rank == 0 and os.environ.get("BENCH_VERBOSE"):
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    nms_stream = torch.cuda.Stream(device=dev)
+
     def hot_path():
-        eng.forward()
-        result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+        # the NMS of the decoded boxes shares nothing with the backbone: it runs on its own stream beside it
+        if args.no_overlap or args.graph:
+            eng.forward(overlap=False)
+            result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+            return
+        cur = torch.cuda.current_stream(dev)
+        nms_stream.wait_stream(cur)
+        with torch.cuda.stream(nms_stream):
+            result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+        eng.forward(overlap=True)
+        cur.wait_stream(nms_stream)
 
     graph = None
     note("inputs ready")
@@ -160,18 +187,39 @@ def main():
         note("graph captured")
 
     def step(i):
+        if pipelined:
+            plan = eng if i % 2 == 0 else eng2
+            cur = torch.cuda.current_stream(dev)
+            geo = plan.geometry_stream()
+            with torch.cuda.stream(geo):
+                geo.wait_event(plan._done)      # the plan's previous batch has left these buffers
+                load_points(i, plan)
+            nms_stream.wait_stream(cur)
+            with torch.cuda.stream(nms_stream):
+                load_boxes(i)
+                result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+            plan.forward(overlap=True, pipelined=True)
+            cur.wait_stream(nms_stream)
+            return
         load(i)
         if graph is not None:
             graph.replay()
         else:
             hot_path()
 
-    for i in range(args.warmup):
-        step(i)
-    # barrier + device sync on both sides, MAX over ranks (openpcdet_amd/dist.py; tests/test_dist_gloo.py runs it at world 2)
-    elapsed = pdist.timed_steps(step, args.steps, device=dev, first=args.warmup)
+    # the convolutions are the critical path: they get the high-priority stream, geometry and NMS fill in around them
+    lo, hi = torch.cuda.Stream.priority_range()
+    conv_stream = torch.cuda.Stream(device=dev, priority=hi) if (pipelined and not args.flat_priority) else torch.cuda.current_stream(dev)
+    conv_stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(conv_stream):
+        for i in range(args.warmup):
+            step(i)
+        # barrier + device sync on both sides, MAX over ranks (openpcdet_amd/dist.py; tests/test_dist_gloo.py runs it at world 2)
+        elapsed = pdist.timed_steps(step, args.steps, device=dev, first=args.warmup)
+    torch.cuda.current_stream(dev).wait_stream(conv_stream)
+    note("stream priority range %s" % ((lo, hi),))
     note("timed region done: %.3f s" % elapsed)
-    assert not eng.overflowed(), "a level overflowed its row capacity"
+    assert not eng.overflowed() and (eng2 is None or not eng2.overflowed()), "a level overflowed its row capacity"
     rows = eng.level_rows()
 
     out = None
@@ -231,7 +279,7 @@ def main():
             "config": {"workload": "CenterPoint nuScenes 10-sweep 300k pts/frame, 0.075 m voxels, VoxelResBackBone8x, "
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
-                       "hip_graph": graph is not None, "rows_per_level": rows},
+                       "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else 3, "plans_in_flight": 2 if pipelined else 1, "rows_per_level": rows},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
                        "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},

@@ -293,17 +293,68 @@ class HotPathEngine:
             for name, fn in self.ops:
                 hook(name, lambda: fn(st))
 
-    def forward(self):
+    _GEOMETRY = ("site_index", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
+
+    def forward(self, overlap=True, pipelined=False):
         """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
-        static buffer) or None.  No host synchronisation."""
+        static buffer) or None.  No host synchronisation.
+
+        overlap: the GEOMETRY of a frame (voxel coordinates, site indices, rulebooks of every level) depends on coordinates
+        only, never on features, so it runs ahead on its own HIP stream while the convolutions of the earlier levels occupy
+        the main stream; a conv waits (stream event) for the last geometry launch that precedes it in plan order.  The conv
+        kernels are latency-bound and leave HBM mostly idle, which is what the bandwidth-bound
+        geometry kernels use.
+        pipelined: for a serving loop that alternates TWO plans (frames i, i+2, ... on one; i+1, i+3, ... on the other): the
+        geometry stream then does not wait for the main stream (so the geometry of frame i+1 runs beside the convolutions of
+        frame i) but only for this plan's own previous forward; the caller loads `points` on `geometry_stream()`."""
         with torch.cuda.device(self.device):
-            st = _lib.stream()
-            self.voxelize(st)
-            self.backbone(st)
+            main = torch.cuda.current_stream(self.device)
+            if not overlap:
+                st = main.cuda_stream
+                self.voxelize(st)
+                self.backbone(st)
+            else:
+                geo = self._geo_stream()
+                if pipelined:
+                    geo.wait_event(self._done)            # the convs of this plan's previous batch read the rulebooks
+                else:
+                    geo.wait_stream(main)                 # the frames were loaded on the main stream
+                g, m = geo.cuda_stream, main.cuda_stream
+                self.voxelize(g)
+                pending = self._geo_events[0]
+                pending.record(geo)
+                i = 1
+                for name, fn in self.ops:
+                    if name in self._GEOMETRY:
+                        fn(g)
+                        pending = self._geo_events[i]
+                        pending.record(geo)
+                        i += 1
+                    else:
+                        if pending is not None:
+                            main.wait_event(pending)
+                            pending = None
+                        fn(m)
+                if pending is not None:
+                    main.wait_event(pending)
+                self._done.record(main)
         if self.want_dense:
             d = self.dense
             return d.view(d.shape[0], d.shape[1] * d.shape[2], d.shape[3], d.shape[4])
         return None
+
+    def _geo_stream(self):
+        if getattr(self, "_geo", None) is None:
+            self._geo = torch.cuda.Stream(device=self.device)
+            n = 1 + sum(1 for name, _ in self.ops if name in self._GEOMETRY)
+            self._geo_events = [torch.cuda.Event() for _ in range(n)]
+            self._done = torch.cuda.Event()
+            self._done.record(torch.cuda.current_stream(self.device))
+        return self._geo
+
+    def geometry_stream(self):
+        with torch.cuda.device(self.device):
+            return self._geo_stream()
 
     # ---- results (these DO synchronise: for tests / reporting, not for the hot loop) ---------------------------------
     def level_rows(self):
