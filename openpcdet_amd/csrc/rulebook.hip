@@ -46,6 +46,17 @@ __device__ __forceinline__ int rank_of(const IndexEntry* __restrict__ idx, long 
     return (int)raw.z + __popcll(bits & ((1ull << bit) - 1ull));
 }
 
+// the same lookup for a run of keys that mostly fall into one word (x-neighbours): the entry is re-loaded only when the
+// word changes, so the 3 x-offsets of a kernel line cost one 16-B load instead of three
+__device__ __forceinline__ int rank_of_cached(const IndexEntry* __restrict__ idx, long long key, long long& cword, uint4& craw) {
+    const long long word = key >> 6;
+    if (word != cword) { craw = *reinterpret_cast<const uint4*>(idx + word); cword = word; }
+    const unsigned long long bits = ((unsigned long long)craw.y << 32) | craw.x;
+    const int bit = (int)(key & 63);
+    if (!((bits >> bit) & 1ull)) return -1;
+    return (int)craw.z + __popcll(bits & ((1ull << bit) - 1ull));
+}
+
 // every kernel takes (n, n_dev): n is the row capacity the grid is sized for, *n_dev (when given) the live row
 // count produced by an earlier kernel on the same stream -- no host round trip for data-dependent sizes
 __device__ __forceinline__ int live_rows(int n, const int* __restrict__ n_dev) {
@@ -107,6 +118,8 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restri
     if (o >= live_rows(n, n_dev)) return;   // nbr keeps the CAPACITY n as its row stride
     const int4 c = reinterpret_cast<const int4*>(coords)[o];
     int k = 0;
+    long long cword = -1;
+    uint4 craw = make_uint4(0u, 0u, 0u, 0u);
     for (int a = 0; a < kd; a++) {
         const int z = c.y + (a - kd / 2) * dd;
         for (int bq = 0; bq < kh; bq++) {
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restri
                 const int x = c.w + (cq - kw / 2) * dw;
                 int v = -1;
                 if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w && c.x >= 0 && c.x < s.b) {
-                    const int r = rank_of(idx, lin_key(c.x, z, y, x, s));
+                    const int r = rank_of_cached(idx, lin_key(c.x, z, y, x, s), cword, craw);
                     if (r >= 0) v = perm ? perm[r] : r;
                 }
                 nbr[(size_t)k * n + o] = v;
@@ -187,16 +200,25 @@ __global__ __launch_bounds__(kBlk) void conv_out_coords_kernel(const IndexEntry*
     const long long w = (long long)blockIdx.x * kBlk + threadIdx.x;
     if (w >= words) return;
     unsigned long long bits = idx[w].bits;
+    if (!bits) return;
     int r = (int)idx[w].prefix;
+    // decode the word's first cell once (64-bit divisions), then walk the set bits with 32-bit carries
+    long long key = w << 6;
+    int x0 = (int)(key % s.w); key /= s.w;
+    int y0 = (int)(key % s.h); key /= s.h;
+    int z0 = (int)(key % s.d);
+    int b0 = (int)(key / s.d);
+    int done = 0;
     while (bits) {
         const int bit = __ffsll((long long)bits) - 1;
         bits &= bits - 1ull;
-        long long key = (w << 6) + bit;
-        const int x = (int)(key % s.w); key /= s.w;
-        const int y = (int)(key % s.h); key /= s.h;
-        const int z = (int)(key % s.d);
-        const int b = (int)(key / s.d);
-        if (r < n_out) reinterpret_cast<int4*>(coords_out)[r] = make_int4(b, z, y, x);
+        x0 += bit - done;
+        done = bit;
+        while (x0 >= s.w) {
+            x0 -= s.w;
+            if (++y0 >= s.h) { y0 = 0; if (++z0 >= s.d) { z0 = 0; b0++; } }
+        }
+        if (r < n_out) reinterpret_cast<int4*>(coords_out)[r] = make_int4(b0, z0, y0, x0);
         r++;
     }
 }
@@ -211,6 +233,8 @@ __global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __re
     if (o >= live_rows(n_out, n_out_dev)) return;
     const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
     int k = 0;
+    long long cword = -1;
+    uint4 craw = make_uint4(0u, 0u, 0u, 0u);
     for (int a = 0; a < g.k[0]; a++) {
         const int z = c.y * g.s[0] - g.p[0] + a * g.dil[0];
         for (int bq = 0; bq < g.k[1]; bq++) {
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __re
                 const int x = c.w * g.s[2] - g.p[2] + cq * g.dil[2];
                 int v = -1;
                 if (z >= 0 && z < g.in.d && y >= 0 && y < g.in.h && x >= 0 && x < g.in.w) {
-                    const int r = rank_of(in_idx, lin_key(c.x, z, y, x, g.in));
+                    const int r = rank_of_cached(in_idx, lin_key(c.x, z, y, x, g.in), cword, craw);
                     if (r >= 0) v = in_perm ? in_perm[r] : r;
                 }
                 nbr[(size_t)k * n_out + o] = v;
