@@ -404,7 +404,7 @@ class BatchedNMS:
         """boxes [S, cap, >=7], scores [S, cap], counts [S] int32 -> (sel [S, post_max] int64 indices into each
         segment's boxes in descending score order, num [S] int32 = min(kept, post_max)); no host sync."""
         S, cap = self.S, self.cap
-        masked = torch.where(self._idx < counts.view(-1, 1), scores, scores.new_full((), float('-inf')))
+        masked = scores.masked_fill(self._idx >= counts.view(-1, 1), float('-inf'))   # scalar as a kernel argument: no H2D copy
         order = masked.sort(1, descending=True)[1]
         torch.gather(boxes[..., :7], 1, order.unsqueeze(-1).expand(S, cap, 7), out=self.sorted_boxes)
         L = _lib.lib()
