@@ -87,8 +87,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
-    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
     ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
                     "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")
     ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the conv stream (A/B switch)")
@@ -280,13 +280,13 @@ def main():
         # HBM bytes per conv launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
         # separate runs, FETCH_SIZE doubled as the gfx950 note prescribes: tools/pmc_traffic.py); null when the file is absent
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_pmc_traffic.json")
-        if os.path.exists(tpath) and B == 8:
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_b%d.json" % B)
+        if os.path.exists(tpath):
             rows_t = [r for r in json.load(open(tpath)) if r["kernel"].startswith("sparse_conv")]
             passes_t = max(1, min(r["launches"] for r in rows_t))
             tot_b = sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] / passes_t for r in rows_t)
             n_l = sum(r["launches"] / passes_t for r in rows_t)
-            traffic, traffic_src = round(tot_b / n_l), "profiles/r01_c_pmc_traffic.json (B=8)"
+            traffic, traffic_src = round(tot_b / n_l), "profiles/" + os.path.basename(tpath)
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "sparse_conv_w32_kernel + sparse_conv_mfma2_kernel (%d conv launches/step)" % conv_launches,
