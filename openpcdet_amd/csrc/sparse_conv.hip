@@ -660,6 +660,7 @@ int conv_impl() {
 }
 
 #include "sparse_conv_w32.h"
+#include "sparse_conv_slab.h"
 
 long long prepared_elems(int cout, int K, int cin, int dtype) {
     if (w32_shape(cin, cout, K, dtype)) {
@@ -814,7 +815,19 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
     if (!prepared_weight || !nbr || !out || (n_in > 0 && !feat_in)) return PVX_ERR_INVALID;
     if ((long long)n_out * cout > 0x7fffffff00ll) return PVX_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    if (w32_shape(cin, cout, kvol, dtype)) {
+    if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
+        int rcs = PVX_ERR_INVALID;
+#define X(ci, co, rc)                                                                                                         \
+    if (cin == ci && cout == co) {                                                                                            \
+        if (dtype == PVX_BF16)                                                                                                \
+            rcs = launch_slab<__bf16, ci, co, rc>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+        else                                                                                                                  \
+            rcs = launch_slab<_Float16, ci, co, rc>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+    }
+        PVX_SLAB_SHAPES(X)
+#undef X
+        if (rcs != PVX_OK) return rcs;
+    } else if (w32_shape(cin, cout, kvol, dtype)) {
         int rc32 = PVX_ERR_INVALID;
 #define X(ci, co)                                                                                                             \
     if (cin == ci && cout == co) {                                                                                            \

@@ -1,0 +1,237 @@
+// Sparse-conv implicit GEMM with the gathered rows staged through LDS as contiguous SLABS -- included by sparse_conv.hip
+// after sparse_conv_w32.h (same weight fragment image, same MFMA, same epilogue).
+//
+// What the register-gather kernels are bound by: every input row is fetched ~15 times through L2,
+// once per output site that has it as a neighbour.  But rows are in ascending key order ((b, z, y, x)), so the neighbours
+// of 256 CONSECUTIVE output sites at kernel offset dz are a nearly contiguous run of input rows -- the same y-lines one
+// z-plane up or down -- and the nine (dy, dx) offsets of one dz all read that same run.  So per tile and per dz the kernel
+//   1. takes min / max of the 9 x 256 rulebook entries of the group (they are in LDS already),
+//   2. streams rows [min, max] into LDS with fully coalesced 16-byte loads (one pass, each row once),
+//   3. feeds the MFMA B operand from LDS: lane (site, half) reads its 16 bytes at (nbr - min) * stride.
+// L2 sees each row ~3 times per layer (once per dz) instead of ~15 and sees streams instead of 32-byte gathers.
+// The row stride in LDS is CIN * 2 + 16 bytes, which spreads consecutive rows over all 64 banks for ds_read_b128.
+// Correctness does not depend on the ordering: a group whose [min, max] span exceeds the LDS capacity (unsorted input
+// such as first-come voxel rows, or a tile that straddles two z-planes) falls back to range-checked buffer gathers.
+#pragma once
+
+template <typename E, int CIN, int COUT, int RCAP>
+__global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
+                                                               const uint4* __restrict__ wfrag, const int* __restrict__ nbr,
+                                                               int n_out, const int* __restrict__ n_out_dev,
+                                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const E* __restrict__ residual,
+                                                               int relu, E* __restrict__ out) {
+    typedef Tiling32<CIN, COUT> TL;
+    constexpr int T = TL::T, S = TL::S, NT = 512, TM = 256, K = 27, GK = 9;
+    constexpr int ROW_U4 = CIN * (int)sizeof(E) / 16, RS_U4 = ROW_U4 + 1;      // row stride in LDS: one extra 16-B slot
+    __shared__ uint4 wlds[GK * TL::GROUP_U4];
+    __shared__ int nlds[K * TM];
+    __shared__ uint4 rlds[RCAP * RS_U4];
+    __shared__ int g_lo[3], g_hi[3];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n_live = live_rows(n_out, n_out_dev);
+    const int ntiles = (n_live + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7) >> 3;
+    const int tile_begin = (int)((long long)ntiles * xcd / 8), tile_end = (int)((long long)ntiles * (xcd + 1) / 8);
+    if (tile_begin + wg_in_xcd >= tile_end) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+    const uint4* __restrict__ feat_u4 = reinterpret_cast<const uint4*>(feat);
+
+    for (int tile = tile_begin + wg_in_xcd; tile < tile_end; tile += wgs_per_xcd) {
+        const int tile0 = tile * TM;
+        __syncthreads();                                   // the previous tile is done with every LDS buffer
+        if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
+        __syncthreads();
+        {   // rulebook slice -> LDS, and the row span of each dz group
+            int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -1, -1, -1 };
+            constexpr int NI = (K * TM + NT - 1) / NT;
+            int tmp[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                const int k = i / TM, site = tile0 + (i - k * TM);
+                int v = -1;
+                if (k < K && site < n_live) v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + site);
+                if (v >= n_in) v = -1;
+                tmp[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                if (i < K * TM) {
+                    nlds[i] = tmp[q];
+                    if (tmp[q] >= 0) {
+                        const int g = (i / TM) / GK;
+#pragma unroll
+                        for (int gg = 0; gg < 3; gg++)
+                            if (g == gg) { lo[gg] = min(lo[gg], tmp[q]); hi[gg] = max(hi[gg], tmp[q]); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int gg = 0; gg < 3; gg++) {
+                int l = lo[gg], h = hi[gg];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { l = min(l, __shfl_xor(l, off)); h = max(h, __shfl_xor(h, off)); }
+                if (lane == 0 && h >= 0) { atomicMin(&g_lo[gg], l); atomicMax(&g_hi[gg], h); }
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+        const int* my_n = nlds + wave * 32 + col;
+
+        for (int g = 0; g < 3; g++) {
+            const int lo = g_lo[g], hi = g_hi[g];
+            if (hi < 0) continue;                          // no pair in this dz group for the whole tile (uniform)
+            const int cnt = hi - lo + 1;
+            const bool fits = cnt <= RCAP;
+            __syncthreads();                               // the previous group's MFMAs are done with wlds / rlds
+            {
+                constexpr int NW = (GK * TL::GROUP_U4 + NT - 1) / NT;
+                uint4 wt[NW];
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    const int i = q * NT + tid;
+                    wt[q] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < GK * TL::GROUP_U4) wt[q] = wfrag[(size_t)g * GK * TL::GROUP_U4 + i];
+                }
+                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT;
+                uint4 rt[NR];
+                const int chunks = fits ? cnt * ROW_U4 : 0;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    const int c = q * NT + tid;
+                    rt[q] = make_uint4(0u, 0u, 0u, 0u);
+                    if (c < chunks) rt[q] = feat_u4[(size_t)lo * ROW_U4 + c];
+                }
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    const int i = q * NT + tid;
+                    if (i < GK * TL::GROUP_U4) wlds[i] = wt[q];
+                }
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    const int c = q * NT + tid;
+                    if (c < chunks) { const int row = c / ROW_U4; rlds[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < GK; kk++) {
+                const int rr = my_n[(g * GK + kk) * TM];
+                if (__ballot(rr >= 0) == 0ull) continue;   // wave-uniform
+                const uint4* wsrc = wlds + kk * TL::GROUP_U4 + lane;
+                uint4 b[S];
+                if (fits) {
+                    const uint4* rsrc_l = rlds + (rr >= 0 ? rr - lo : 0) * RS_U4 + half;
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        b[s] = rsrc_l[2 * s];
+                        if (rr < 0) b[s] = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                } else {
+                    const unsigned voff = rr >= 0 ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
+#pragma unroll
+                    for (int s = 0; s < S; s++)
+                        b[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0));
+                }
+#pragma unroll
+                for (int s = 0; s < S; s++)
+#pragma unroll
+                    for (int t = 0; t < T; t++) acc[t] = Mfma32<E>::run(wsrc[(s * T + t) * 64], b[s], acc[t]);
+            }
+        }
+
+        // epilogue (as sparse_conv_w32_kernel): lane (site col, half) holds output channels 32 t + 16 half + [0, 16)
+        const int site = tile0 + wave * 32 + col;
+        if (site < n_live) {
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const int co0 = 32 * t + 16 * half;
+                if (co0 >= COUT) continue;
+                const size_t base = (size_t)site * COUT + co0;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = acc[t][q];
+                if (bias) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 bb = *reinterpret_cast<const float4*>(bias + co0 + 4 * q4);
+                        v[4 * q4] += bb.x; v[4 * q4 + 1] += bb.y; v[4 * q4 + 2] += bb.z; v[4 * q4 + 3] += bb.w;
+                    }
+                }
+                if (scale) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 sc = *reinterpret_cast<const float4*>(scale + co0 + 4 * q4);
+                        const float4 sh = *reinterpret_cast<const float4*>(shift + co0 + 4 * q4);
+                        v[4 * q4] = v[4 * q4] * sc.x + sh.x; v[4 * q4 + 1] = v[4 * q4 + 1] * sc.y + sh.y;
+                        v[4 * q4 + 2] = v[4 * q4 + 2] * sc.z + sh.z; v[4 * q4 + 3] = v[4 * q4 + 3] * sc.w + sh.w;
+                    }
+                }
+                if (residual) {
+                    const u32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base));
+                    const u32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base + 8));
+                    E re[16];
+                    __builtin_memcpy(re, &r0, 16);
+                    __builtin_memcpy(re + 8, &r1, 16);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] += (float)re[q];
+                }
+                E oe[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) oe[q] = (E)(relu ? fmaxf(v[q], 0.f) : v[q]);
+                u32x4 o0, o1;
+                __builtin_memcpy(&o0, oe, 16);
+                __builtin_memcpy(&o1, oe + 8, 16);
+                __builtin_nontemporal_store(o0, reinterpret_cast<u32x4*>(out + base));
+                __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(out + base + 8));
+            }
+        }
+    }
+}
+
+// shapes with a slab form: K = 27 (3 x 3 x 3), LDS = 9 offsets of weights + the rulebook slice + RCAP rows
+#define PVX_SLAB_SHAPES(X) X(32, 32, 384) X(32, 64, 384) X(64, 64, 384)
+
+inline bool slab_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PVX_CONV_SLAB"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
+inline bool slab_shape(int cin, int cout, int K, int dtype) {
+    if (dtype == PVX_F32 || K != 27 || !slab_enabled()) return false;
+#define X(ci, co, rc) if (cin == ci && cout == co) return true;
+    PVX_SLAB_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <typename E, int CIN, int COUT, int RCAP>
+int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n_out, const int* n_out_dev, const float* bias,
+                const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
+    const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
+    if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_conv_slab_kernel<E, CIN, COUT, RCAP>, 512, 0) != hipSuccess || nb < 1)
+            nb = 1;
+        per_cu = nb > 2 ? 2 : nb;
+    }
+    int grid = num_cus() * per_cu;
+    const int tiles = PVX_CDIV(n_out, 256);
+    if (grid > tiles) grid = (tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                       (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual, relu,
+                       (E*)out);
+    return PVX_OK;
+}

@@ -5,7 +5,7 @@ timeout -k 10 300 python -u -m pytest tests/test_gpu_spconv.py tests/test_gpu_en
 tail -1 gpurun_out/q_tests.log
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/q_prof
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/q_prof -o r -- python3 bench.py --cpu-frames 0 --steps 20 --warmup 5 > gpurun_out/q_bench.json 2> gpurun_out/q_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/q_prof -o r -- python3 bench.py --cpu-frames 0 --batch 8 --pool 8 --no-overlap --steps 20 --warmup 5 > gpurun_out/q_bench.json 2> gpurun_out/q_bench.err
 python3 - <<'PY'
 import json, sqlite3
 d = json.loads(open("gpurun_out/q_bench.json").read().strip().splitlines()[-1])
