@@ -88,10 +88,14 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
         const int* my_n = nlds + wave * 32 + col;
 
         for (int g = 0; g < 3; g++) {
-            const int lo = g_lo[g], hi = g_hi[g];
+            const int hi = g_hi[g];
             if (hi < 0) continue;                          // no pair in this dz group for the whole tile (uniform)
-            const int cnt = hi - lo + 1;
-            const bool fits = cnt <= RCAP;
+            // rows [lo, lo + cnt) go to LDS; when the span is longer than the LDS window, the window is centred in it and the
+            // sites whose neighbour falls outside read theirs with a buffer gather instead (per lane)
+            const int span = g_hi[g] - g_lo[g] + 1;
+            const int cnt = span <= RCAP ? span : RCAP;
+            const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
+            const bool all_in = span <= RCAP;
             __syncthreads();                               // the previous group's MFMAs are done with wlds / rlds
             {
                 constexpr int NW = (GK * TL::GROUP_U4 + NT - 1) / NT;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
                 }
                 constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT;
                 uint4 rt[NR];
-                const int chunks = fits ? cnt * ROW_U4 : 0;
+                const int chunks = cnt * ROW_U4;
 #pragma unroll
                 for (int q = 0; q < NR; q++) {
                     const int c = q * NT + tid;
@@ -129,18 +133,21 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
                 if (__ballot(rr >= 0) == 0ull) continue;   // wave-uniform
                 const uint4* wsrc = wlds + kk * TL::GROUP_U4 + lane;
                 uint4 b[S];
-                if (fits) {
-                    const uint4* rsrc_l = rlds + (rr >= 0 ? rr - lo : 0) * RS_U4 + half;
+                const int local = rr - lo;
+                const bool in_lds = rr >= 0 && local >= 0 && local < cnt;
+                const uint4* rsrc_l = rlds + (in_lds ? local : 0) * RS_U4 + half;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    b[s] = rsrc_l[2 * s];
+                    if (!in_lds) b[s] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                if (!all_in && __ballot(rr >= 0 && !in_lds) != 0ull) {      // wave-uniform: somebody's neighbour is outside the window
+                    const unsigned voff = (rr >= 0 && !in_lds) ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
 #pragma unroll
                     for (int s = 0; s < S; s++) {
-                        b[s] = rsrc_l[2 * s];
-                        if (rr < 0) b[s] = make_uint4(0u, 0u, 0u, 0u);
+                        const uint4 gth = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0));
+                        b[s].x |= gth.x; b[s].y |= gth.y; b[s].z |= gth.z; b[s].w |= gth.w;     // out-of-range lanes loaded zeros
                     }
-                } else {
-                    const unsigned voff = rr >= 0 ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
-#pragma unroll
-                    for (int s = 0; s < S; s++)
-                        b[s] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0));
                 }
 #pragma unroll
                 for (int s = 0; s < S; s++)
@@ -198,12 +205,15 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
     }
 }
 
-// shapes with a slab form: K = 27 (3 x 3 x 3), LDS = 9 offsets of weights + the rulebook slice + RCAP rows
-#define PVX_SLAB_SHAPES(X) X(32, 32, 384) X(32, 64, 384) X(64, 64, 384)
+// shapes with a slab form: K = 27 (3 x 3 x 3), LDS = 9 offsets of weights + the rulebook slice + RCAP rows.
+// Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
+// MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
+// on the register-gather kernel.
+#define PVX_SLAB_SHAPES(X) X(64, 64, 384)
 
 inline bool slab_enabled() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("PVX_CONV_SLAB"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("PVX_CONV_SLAB"); v = e ? atoi(e) : 1; }   // PVX_CONV_SLAB=0: A/B switch
     return v != 0;
 }
 
