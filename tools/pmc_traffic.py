@@ -14,12 +14,11 @@ def load(d):
     cnt = collections.Counter()
     for r in csv.DictReader(open(glob.glob(d + '/*counter_collection.csv')[0])):
         n = r['Kernel_Name']
-        if 'sparse_conv_w32' in n:
-            p = n.split('kernelI')[1].split('E')
-            key = 'sparse_conv_w32<%s,%s>' % (p[0][-3:].lstrip('Li').lstrip('i') or p[0], p[1].lstrip('Li'))
+        if 'sparse_conv_w32' in n or 'sparse_conv_slab' in n:
+            kind = 'sparse_conv_slab' if 'sparse_conv_slab' in n else 'sparse_conv_w32'
             a = n.split('kernelIDF16b')[1] if 'kernelIDF16b' in n else n
             nums = [t for t in a.replace('E', ' ').replace('Li', ' ').split() if t.isdigit()]
-            key = 'sparse_conv_w32<cin=%s,cout=%s>' % (nums[0], nums[1])
+            key = '%s<cin=%s,cout=%s>' % (kind, nums[0], nums[1])
         elif 'sparse_conv_mfma2' in n:
             key = 'sparse_conv_mfma2<cin=16,cout=%s>' % ('32' if 'ELi32E' in n else '16')
         else:
