@@ -240,6 +240,15 @@ int pvx_unique_sites(const int* coords, int n, const int* n_dev, int batch, cons
                      int out_capacity, int* coords_out, int* inverse, int* n_unique, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Rows into ascending key order: for every live row i with rank r in `index` (built by pvx_site_index_build over the
+ * same coords, which must be unique), coords_out[r] = coords[i], rows_out[r] = rows[i] (row_bytes per row, a multiple
+ * of 16) and rank_out[i] = r (optional).  Out of place.  After it the index addresses the sorted rows directly (perm =
+ * NULL in pvx_subm_rulebook / pvx_conv_out_rulebook).  The reference has no counterpart: spconv leaves hard voxels in
+ * the voxelizer's first-come order (data_processor.py:200-247) and pays for it in its gather kernels; this is the
+ * serving plan's locality step (openpcdet_amd/engine.py). */
+int pvx_sort_sites(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                   const void* rows, int row_bytes, int* coords_out, void* rows_out, int* rank_out, void* stream);
+
 /* Submanifold rulebook: nbr[k][o] = row of the site at coords[o] + (k - K/2) * dilation, or -1.  Output rows
  * are the input rows (SubMConv3d, spconv_backbone.py:12,39-46).  ksize odd per axis. */
 int pvx_subm_rulebook(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,

@@ -56,6 +56,8 @@ SIGNATURES = {
     "pvx_scatter_sum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_unique_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    "pvx_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

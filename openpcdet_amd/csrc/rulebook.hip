@@ -481,4 +481,43 @@ extern "C" int pvx_unique_sites(const int* coords, int n, const int* n_dev, int 
     return PVX_OK;
 }
 
+// ---- rows into key order ---------------------------------------------------------------------------------------
+// Hard voxels arrive in first-come order, i.e. scattered over the grid.  The serving plan moves them into ascending key
+// order once (rank = the site index's popcount prefix, no sort), so that the 32-site tiles of the level-0 convolutions
+// and the rulebook / strided-output kernels walk neighbouring cells: measured on the nuScenes frame, the share of
+// (tile, offset) pairs with any neighbour at all drops from 0.51 to 0.36.
+namespace {
+
+__global__ __launch_bounds__(kBlk) void sort_sites_kernel(const int* __restrict__ coords, int n_cap, const int* __restrict__ n_dev,
+                                                           Dims s, const IndexEntry* __restrict__ idx,
+                                                           const uint4* __restrict__ rows, int row_u4, int* __restrict__ coords_out,
+                                                           uint4* __restrict__ rows_out, int* __restrict__ rank_out) {
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    if (i >= live_rows(n_cap, n_dev)) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    int r = -1;
+    if (c.x >= 0 && c.x < s.b && c.y >= 0 && c.y < s.d && c.z >= 0 && c.z < s.h && c.w >= 0 && c.w < s.w)
+        r = rank_of(idx, lin_key(c.x, c.y, c.z, c.w, s));
+    if (rank_out) rank_out[i] = r;
+    if (r < 0 || r >= n_cap) return;
+    reinterpret_cast<int4*>(coords_out)[r] = c;
+    for (int q = 0; q < row_u4; q++) rows_out[(size_t)r * row_u4 + q] = rows[(size_t)i * row_u4 + q];
+}
+
+}  // namespace
+
+extern "C" int pvx_sort_sites(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                              const void* rows, int row_bytes, int* coords_out, void* rows_out, int* rank_out, void* stream) {
+    if (n < 0 || !shape_dhw || row_bytes <= 0 || (row_bytes & 15)) return PVX_ERR_INVALID;
+    if (n == 0) return PVX_OK;
+    if (!coords || !index || !rows || !coords_out || !rows_out || coords == coords_out || rows == rows_out) return PVX_ERR_INVALID;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    hipLaunchKernelGGL(sort_sites_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
+                       (const IndexEntry*)index, (const uint4*)rows, row_bytes / 16, coords_out, (uint4*)rows_out, rank_out);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
 #include "dynamic_voxelize.h"

@@ -97,13 +97,16 @@ class _Level:
 class HotPathEngine:
     def __init__(self, backbone, batch_size, point_cloud_range, voxel_size, max_points_per_voxel, max_voxels_per_frame,
                  num_point_features, max_points_per_frame, dtype=torch.bfloat16, device="cuda", level_capacity_factor=None,
-                 want_dense=True):
+                 want_dense=True, sort_input=True):
         """backbone: a VoxelBackBone8x / VoxelResBackBone8x (this package's or a state-dict-compatible tree) in eval mode.
         level_capacity_factor: row capacity of each strided conv's output relative to its input's capacity.  None (the
         default) sizes every level for the worst case, prod_j ceil(k_j / s_j) outputs per input site (8 for k3 s2),
         capped by the number of grid cells -- never overflows, costs memory and idle workgroups.  Dense LiDAR frames give
         ~1x, isolated voxels up to ~3.4x; with an explicit factor, rows beyond the capacity are dropped and
-        `overflowed()` reports it."""
+        `overflowed()` reports it.
+        sort_input: move the voxels from the voxelizer's first-come order into key order before the first conv
+        (pvx_sort_sites; the level-0 tiles then walk neighbouring cells).  `stage_output` still reports level-0 rows in
+        first-come order.  Needs 16-byte-multiple feature rows, otherwise it is switched off."""
         assert not backbone.training, "the plan folds BatchNorm running statistics: call backbone.eval() first"
         assert dtype in _lib.DTYPE_CODE
         self.L = _lib.lib()
@@ -117,6 +120,7 @@ class HotPathEngine:
         self.vsize = (ctypes.c_float * 3)(*[float(v) for v in voxel_size])
         self.range = (ctypes.c_float * 6)(*[float(v) for v in point_cloud_range])
         self.want_dense = want_dense
+        self.sort_input = bool(sort_input)
         dev = self.device
         with torch.cuda.device(dev):
             self._build(backbone, level_capacity_factor)
@@ -162,9 +166,16 @@ class HotPathEngine:
         if self.dtype != torch.float32 and L.pvx_sparse_conv_uses_mfma(16, first.out_channels, self.code) and self.C <= 16:
             self.cin0 = 16
 
-        lvl = _Level(shape0, B * self.max_voxels, B, dev, with_perm=True)
+        row_bytes0 = self.cin0 * torch.empty((), dtype=self.dtype).element_size()
+        self.sort_input = self.sort_input and row_bytes0 % 16 == 0
+        lvl = _Level(shape0, B * self.max_voxels, B, dev, with_perm=not self.sort_input)
         self.levels = [lvl]
         self.feat0 = torch.zeros((lvl.cap, self.cin0), dtype=self.dtype, device=dev)
+        # what the voxelizer writes: the level's own rows, or first-come staging rows that pvx_sort_sites moves into key order
+        self.vox_coords, self.vox_feat = lvl.coords, self.feat0
+        if self.sort_input:
+            self.vox_coords, self.vox_feat = torch.zeros_like(lvl.coords), torch.zeros_like(self.feat0)
+            self.rank0 = torch.full((lvl.cap,), -1, dtype=torch.int32, device=dev)
         self.points = torch.full((B, self.n_pts_cap, self.C), float('nan'), dtype=torch.float32, device=dev)
         self.num_voxels = torch.zeros(B, dtype=torch.int32, device=dev)
         self.vox_ws = _lib.workspace(L.pvx_voxelize_batch_workspace_bytes(B, self.n_pts_cap, self.max_voxels, self.T), dev)
@@ -210,9 +221,13 @@ class HotPathEngine:
 
         # site index of the input level
         self._n_unique0 = torch.zeros(1, dtype=torch.int32, device=dev)
-        a0 = (_lib.ptr(lvl.coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index), _lib.ptr(lvl.perm),
+        a0 = (_lib.ptr(self.vox_coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index), _lib.ptr(lvl.perm),
               _lib.ptr(self._n_unique0), _lib.ptr(lvl.ws), lvl.ws.numel())
         self.ops.append(("site_index", lambda st, a=a0: _lib.check(L.pvx_site_index_build(*a, st), "pvx_site_index_build")))
+        if self.sort_input:
+            a0s = (_lib.ptr(self.vox_coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index),
+                   _lib.ptr(self.vox_feat), row_bytes0, _lib.ptr(lvl.coords), _lib.ptr(self.feat0), _lib.ptr(self.rank0))
+            self.ops.append(("sort_sites", lambda st, a=a0s: _lib.check(L.pvx_sort_sites(*a, st), "pvx_sort_sites")))
 
         for stage in stages:
             for item in stage:
@@ -280,7 +295,7 @@ class HotPathEngine:
         st = _lib.stream() if st is None else st
         lvl = self.levels[0]
         _lib.check(L.pvx_voxelize_mean_batch(_lib.ptr(self.points), self.B, self.n_pts_cap, self.C, self.vsize, self.range,
-                                             self.T, self.max_voxels, lvl.cap, _lib.ptr(lvl.coords), _lib.ptr(self.feat0),
+                                             self.T, self.max_voxels, lvl.cap, _lib.ptr(self.vox_coords), _lib.ptr(self.vox_feat),
                                              self.cin0, self.code, _lib.ptr(self.num_voxels), _lib.ptr(lvl.n_dev),
                                              _lib.ptr(self.vox_ws), self.vox_ws.numel(), st), "pvx_voxelize_mean_batch")
 
@@ -293,7 +308,7 @@ class HotPathEngine:
             for name, fn in self.ops:
                 hook(name, lambda: fn(st))
 
-    _GEOMETRY = ("site_index", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
+    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
 
     def forward(self, overlap=True, pipelined=False):
         """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
@@ -368,6 +383,9 @@ class HotPathEngine:
         """(indices [n, 4], features [n, C]) of stage i (0 = conv_input, 1..4 = x_conv1..4, 5 = conv_out)"""
         lvl, feat, _ = self.stage_outputs[i]
         n = min(int(lvl.n_dev.item()), lvl.cap)
+        if self.sort_input and lvl is self.levels[0]:      # level-0 rows live in key order: report them first-come, as spconv would
+            r = self.rank0[:n].long()
+            return lvl.coords[r], feat[r]
         return lvl.coords[:n], feat[:n]
 
     def conv_flops(self):

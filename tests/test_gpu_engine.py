@@ -199,3 +199,65 @@ def test_batched_nms_plan_vs_oracle(cuda_device):
         assert num[s] == len(want)
         if margin > 1e-6:
             assert np.array_equal(sel[s, :num[s]], want)
+
+
+def test_sort_sites_entry_point(cuda_device):
+    """pvx_sort_sites: rows land at the rank of their key (np.lexsort order), bytes unchanged, rank_out is the map"""
+    import ctypes
+    from openpcdet_amd import _lib
+    L = _lib.lib()
+    r = np.random.default_rng(4)
+    B, D, H, W, n, cap = 2, 5, 40, 37, 6000, 6400
+    cells = r.choice(B * D * H * W, n, replace=False)
+    c = np.stack(np.unravel_index(cells, (B, D, H, W)), 1).astype(np.int32)        # unique, shuffled
+    rows = r.integers(0, 2 ** 31 - 1, (cap, 8), dtype=np.int32)                     # 32-byte rows of arbitrary bits
+    coords = torch.zeros((cap, 4), dtype=torch.int32, device=cuda_device)
+    coords[:n] = torch.from_numpy(c).to(cuda_device)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=cuda_device)
+    shape = _lib.int3([D, H, W])
+    index = torch.empty(L.pvx_site_index_bytes(B, shape), dtype=torch.uint8, device=cuda_device)
+    ws = _lib.workspace(L.pvx_site_index_workspace_bytes(B, shape), cuda_device)
+    nu = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    _lib.check(L.pvx_site_index_build(_lib.ptr(coords), cap, _lib.ptr(n_dev), B, shape, _lib.ptr(index), None, _lib.ptr(nu),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "pvx_site_index_build")
+    src = torch.from_numpy(rows).to(cuda_device)
+    c_out = torch.full((cap, 4), -7, dtype=torch.int32, device=cuda_device)
+    r_out = torch.full((cap, 8), -7, dtype=torch.int32, device=cuda_device)
+    rank = torch.full((cap,), -7, dtype=torch.int32, device=cuda_device)
+    _lib.check(L.pvx_sort_sites(_lib.ptr(coords), cap, _lib.ptr(n_dev), B, shape, _lib.ptr(index), _lib.ptr(src), 32,
+                                _lib.ptr(c_out), _lib.ptr(r_out), _lib.ptr(rank), _lib.stream()), "pvx_sort_sites")
+    torch.cuda.synchronize()
+    order = np.lexsort((c[:, 3], c[:, 2], c[:, 1], c[:, 0]))
+    assert int(nu.item()) == n
+    assert np.array_equal(c_out[:n].cpu().numpy(), c[order])
+    assert np.array_equal(r_out[:n].cpu().numpy(), rows[:n][order])
+    want_rank = np.empty(n, np.int32); want_rank[order] = np.arange(n, dtype=np.int32)
+    assert np.array_equal(rank[:n].cpu().numpy(), want_rank)
+    assert (c_out[n:] == -7).all() and (rank[n:] == -7).all()                       # rows beyond the live count untouched
+    # argument checks: in place and odd row sizes are refused
+    assert L.pvx_sort_sites(_lib.ptr(coords), cap, _lib.ptr(n_dev), B, shape, _lib.ptr(index), _lib.ptr(src), 20,
+                            _lib.ptr(c_out), _lib.ptr(r_out), None, _lib.stream()) != 0
+    assert L.pvx_sort_sites(_lib.ptr(coords), cap, _lib.ptr(n_dev), B, shape, _lib.ptr(index), _lib.ptr(src), 32,
+                            _lib.ptr(coords), _lib.ptr(r_out), None, _lib.stream()) != 0
+
+
+def test_engine_sorted_input_equals_first_come(cuda_device):
+    """the key-ordered plan and the first-come plan give the same rows at every stage (bf16: identical sums per site,
+    because a site's 27 neighbours are accumulated in offset order either way) and the same BEV map"""
+    cfg = SMALL
+    frames = [synth.config_cloud("nuscenes_centerpoint", seed, n_points=n) for seed, n in ((41, 30000), (42, 9000))]
+    net = make_backbone(backbones.VoxelResBackBone8x, cfg, 9, cuda_device)
+    outs = []
+    for sort in (True, False):
+        eng = engine.HotPathEngine(net, 2, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], 30000,
+                                   dtype=torch.bfloat16, device=cuda_device, sort_input=sort)
+        assert eng.sort_input == sort
+        eng.load_points([torch.from_numpy(f).to(cuda_device) for f in frames])
+        bev = eng.forward().clone()
+        torch.cuda.synchronize()
+        outs.append((bev, [tuple(t.clone() for t in eng.stage_output(i)) for i in range(6)]))
+    (bev_s, st_s), (bev_f, st_f) = outs
+    for i in range(6):
+        assert torch.equal(st_s[i][0], st_f[i][0]), "stage %d coordinates" % i
+        assert torch.equal(st_s[i][1], st_f[i][1]), "stage %d features" % i
+    assert torch.equal(bev_s, bev_f)
