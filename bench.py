@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
     ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
                     "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")
@@ -111,13 +112,13 @@ def main():
     B, P = args.batch, max(args.pool, args.batch)
     net = build_model(cfg, dev)
     eng = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
-                               dtype=torch.bfloat16, device=dev, level_capacity_factor=2.0)
+                               dtype=torch.bfloat16, device=dev, level_capacity_factor=args.cap_factor)
     nms = engine.BatchedNMS(B * HEADS, BOXES_PER_HEAD, NMS_THRESH, NMS_POST, device=dev)
     pipelined = not (args.no_overlap or args.graph or args.no_pipeline)
     eng2 = None
     if pipelined:   # two plans alternate so that the geometry of batch i+1 runs beside the convolutions of batch i
         eng2 = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
-                                    dtype=torch.bfloat16, device=dev, level_capacity_factor=2.0)
+                                    dtype=torch.bfloat16, device=dev, level_capacity_factor=args.cap_factor)
     frames, boxes, scores, counts = make_inputs(cfg, rank, P, dev)
     # static NMS inputs of one step (what the dense head would have decoded for the B frames)
     s_boxes = torch.zeros((B * HEADS, BOXES_PER_HEAD, 9), device=dev)

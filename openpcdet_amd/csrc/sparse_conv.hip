@@ -363,12 +363,12 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
                 if (k < K && site < n_live && !(dbg & 16)) v = nbr[(size_t)k * n_out + site];
                 tmp[q] = v;
             }
-            uint4 wtmp[RESIDENT ? 1 : PL::WREG];
+            u32x4 wtmp[RESIDENT ? 1 : PL::WREG];
             if (!RESIDENT) {
 #pragma unroll
                 for (int q = 0; q < PL::WREG; q++) {
                     const int i = q * NT + tid;
-                    if (i < PL::CHUNK_U4 && i < total_u4) wtmp[q] = wfrag[i];
+                    if (i < PL::CHUNK_U4 && i < total_u4) wtmp[q] = reinterpret_cast<const u32x4*>(wfrag)[i];
                 }
             }
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
 #pragma unroll
                 for (int q = 0; q < PL::WREG; q++) {
                     const int i = q * NT + tid;
-                    if (i < PL::CHUNK_U4 && i < total_u4) wlds[i] = wtmp[q];
+                    if (i < PL::CHUNK_U4 && i < total_u4) reinterpret_cast<u32x4*>(wlds)[i] = wtmp[q];
                 }
             }
         }
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
             for (int t = 0; t < T; t++) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x4 ring[D][S][MT];
         int act[D];
-        uint4 wreg[RESIDENT ? 1 : PL::WREG];
+        u32x4 wreg[RESIDENT ? 1 : PL::WREG];   // native vectors: HIP's uint4 struct is copied by memcpy, which kept this array
+                                             // an alloca that the backend then parked in LDS (bank conflicts, serialised loads)
         const int* my_n = nlds + wave * (16 * MT) + ls;
 
         // gathers of group g into one register set; act != 0 <=> some site of the wave has a valid neighbour.
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
 #pragma unroll
                             for (int q = 0; q < PL::WREG; q++) {
                                 const int i = q * NT + tid;
-                                if (i < PL::CHUNK_U4 && next0 + i < total_u4) wreg[q] = wfrag[next0 + i];
+                                if (i < PL::CHUNK_U4 && next0 + i < total_u4) wreg[q] = reinterpret_cast<const u32x4*>(wfrag)[next0 + i];
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
 #pragma unroll
                                     for (int qq = 0; qq < PL::WREG; qq++) {
                                         const int i = qq * NT + tid;
-                                        if (i < PL::CHUNK_U4 && c1 * PL::CHUNK_U4 + i < total_u4) dst[i] = wreg[qq];
+                                        if (i < PL::CHUNK_U4 && c1 * PL::CHUNK_U4 + i < total_u4) reinterpret_cast<u32x4*>(dst)[i] = wreg[qq];
                                     }
                                 }
                                 if (!(dbg & 4)) __syncthreads();

@@ -130,13 +130,13 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                 if (k < K && site < n_live && !(dbg & 16)) v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + site);   // streamed once: keep L2 for the gathered rows
                 tmp[q] = v;
             }
-            uint4 wtmp[RESIDENT ? 1 : PL::WREG];
+            u32x4 wtmp[RESIDENT ? 1 : PL::WREG];
             if (!RESIDENT) {
 #pragma unroll
                 for (int q = 0; q < PL::WREG; q++) {
                     const int i = q * NT + tid;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < PL::CHUNK_U4 && i < total_u4) v = wfrag[i];
+                    u32x4 v = { 0u, 0u, 0u, 0u };
+                    if (i < PL::CHUNK_U4 && i < total_u4) v = reinterpret_cast<const u32x4*>(wfrag)[i];
                     wtmp[q] = v;
                 }
             }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
 #pragma unroll
                 for (int q = 0; q < PL::WREG; q++) {
                     const int i = q * NT + tid;
-                    if (i < PL::CHUNK_U4 && i < total_u4) wlds[i] = wtmp[q];
+                    if (i < PL::CHUNK_U4 && i < total_u4) reinterpret_cast<u32x4*>(wlds)[i] = wtmp[q];
                 }
             }
         }
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                 for (int q = 0; q < 16; q++) acc[m][t][q] = 0.f;
         u32x4 ring[D][S][MT];
         int act[D];
-        uint4 wreg[RESIDENT ? 1 : PL::WREG];
+        u32x4 wreg[RESIDENT ? 1 : PL::WREG];   // native vectors: HIP's uint4 struct is copied by memcpy, which kept this array
+                                             // an alloca that the backend then parked in LDS (bank conflicts, serialised loads)
         uint4 wa[2][T];
         const int* my_n = nlds + wave * (32 * MT) + col;
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
 #pragma unroll
                             for (int q = 0; q < PL::WREG; q++) {
                                 const int i = q * NT + tid;
-                                if (i < PL::CHUNK_U4 && next0 + i < total_u4) wreg[q] = wfrag[next0 + i];
+                                if (i < PL::CHUNK_U4 && next0 + i < total_u4) wreg[q] = reinterpret_cast<const u32x4*>(wfrag)[next0 + i];
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
 #pragma unroll
                                     for (int qq = 0; qq < PL::WREG; qq++) {
                                         const int i = qq * NT + tid;
-                                        if (i < PL::CHUNK_U4 && c1 * PL::CHUNK_U4 + i < total_u4) dst[i] = wreg[qq];
+                                        if (i < PL::CHUNK_U4 && c1 * PL::CHUNK_U4 + i < total_u4) reinterpret_cast<u32x4*>(dst)[i] = wreg[qq];
                                     }
                                 }
                                 if (!(dbg & 4)) __syncthreads();
