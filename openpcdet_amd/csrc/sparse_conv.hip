@@ -818,12 +818,12 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
     hipStream_t st = (hipStream_t)stream;
     if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
         int rcs = PVX_ERR_INVALID;
-#define X(ci, co, rc)                                                                                                         \
+#define X(ci, co, rc, sm)                                                                                                     \
     if (cin == ci && cout == co) {                                                                                            \
         if (dtype == PVX_BF16)                                                                                                \
-            rcs = launch_slab<__bf16, ci, co, rc>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+            rcs = launch_slab<__bf16, ci, co, rc, sm>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
         else                                                                                                                  \
-            rcs = launch_slab<_Float16, ci, co, rc>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+            rcs = launch_slab<_Float16, ci, co, rc, sm>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
     }
         PVX_SLAB_SHAPES(X)
 #undef X

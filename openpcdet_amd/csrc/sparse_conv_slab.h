@@ -205,11 +205,212 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
     }
 }
 
+// The same idea for the layers whose weights do not fit LDS nine offsets at a time (>= 16 KiB per offset): ONE offset of weights
+// in LDS, the next one prefetched into registers while the MFMAs of the current one run (two barriers per offset), the row
+// slab of the dz group loaded once per group as above.  All staging arrays are native vectors (an array of HIP's uint4 struct
+// that is carried around a loop stays an alloca and ends up in scratch or LDS).
+template <typename E, int CIN, int COUT, int RCAP>
+__global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
+                                                                      const uint4* __restrict__ wfrag_, const int* __restrict__ nbr,
+                                                                      int n_out, const int* __restrict__ n_out_dev,
+                                                                      const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, const E* __restrict__ residual,
+                                                                      int relu, E* __restrict__ out) {
+    typedef Tiling32<CIN, COUT> TL;
+    constexpr int T = TL::T, S = TL::S, NT = 512, TM = 256, K = 27, GK = 9;
+    constexpr int ROW_U4 = CIN * (int)sizeof(E) / 16, RS_U4 = ROW_U4 + 1;
+    constexpr int NW = TL::GROUP_U4 / NT;
+    static_assert(TL::GROUP_U4 % NT == 0, "one offset of weights must divide over the workgroup");
+    __shared__ u32x4 wlds[TL::GROUP_U4];
+    __shared__ int nlds[K * TM];
+    __shared__ u32x4 rlds[RCAP * RS_U4];
+    __shared__ int g_lo[3], g_hi[3];
+    const u32x4* __restrict__ wfrag = reinterpret_cast<const u32x4*>(wfrag_);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int n_live = live_rows(n_out, n_out_dev);
+    const int ntiles = (n_live + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7) >> 3;
+    const int tile_begin = (int)((long long)ntiles * xcd / 8), tile_end = (int)((long long)ntiles * (xcd + 1) / 8);
+    if (tile_begin + wg_in_xcd >= tile_end) return;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (int)feat_bytes, 0x00020000);
+    const u32x4* __restrict__ feat_u4 = reinterpret_cast<const u32x4*>(feat);
+    const u32x4 zero4 = { 0u, 0u, 0u, 0u };
+
+    for (int tile = tile_begin + wg_in_xcd; tile < tile_end; tile += wgs_per_xcd) {
+        const int tile0 = tile * TM;
+        __syncthreads();
+        if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
+        __syncthreads();
+        {
+            int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -1, -1, -1 };
+            constexpr int NI = (K * TM + NT - 1) / NT;
+            int tmp[NI];
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                const int k = i / TM, site = tile0 + (i - k * TM);
+                int v = -1;
+                if (k < K && site < n_live) v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + site);
+                if (v >= n_in) v = -1;
+                tmp[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < NI; q++) {
+                const int i = q * NT + tid;
+                if (i < K * TM) {
+                    nlds[i] = tmp[q];
+                    if (tmp[q] >= 0) {
+                        const int g = (i / TM) / GK;
+#pragma unroll
+                        for (int gg = 0; gg < 3; gg++)
+                            if (g == gg) { lo[gg] = min(lo[gg], tmp[q]); hi[gg] = max(hi[gg], tmp[q]); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int gg = 0; gg < 3; gg++) {
+                int l = lo[gg], h = hi[gg];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { l = min(l, __shfl_xor(l, off)); h = max(h, __shfl_xor(h, off)); }
+                if (lane == 0 && h >= 0) { atomicMin(&g_lo[gg], l); atomicMax(&g_hi[gg], h); }
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
+        const int* my_n = nlds + wave * 32 + col;
+
+        for (int g = 0; g < 3; g++) {
+            if (g_hi[g] < 0) continue;
+            const int span = g_hi[g] - g_lo[g] + 1;
+            const int cnt = span <= RCAP ? span : RCAP;
+            const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
+            const bool all_in = span <= RCAP;
+            __syncthreads();                               // the previous group is done with wlds / rlds
+            u32x4 wreg[NW];
+            {
+                const u32x4* w0 = wfrag + (size_t)(g * GK) * TL::GROUP_U4;
+                u32x4 wt[NW];
+#pragma unroll
+                for (int q = 0; q < NW; q++) wt[q] = w0[q * NT + tid];
+                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT;
+                u32x4 rt[NR];
+                const int chunks = cnt * ROW_U4;
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    const int c = q * NT + tid;
+                    rt[q] = zero4;
+                    if (c < chunks) rt[q] = feat_u4[(size_t)lo * ROW_U4 + c];
+                }
+#pragma unroll
+                for (int q = 0; q < NW; q++) wreg[q] = w0[TL::GROUP_U4 + q * NT + tid];      // offset 1 of the group, in flight
+#pragma unroll
+                for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wt[q];
+#pragma unroll
+                for (int q = 0; q < NR; q++) {
+                    const int c = q * NT + tid;
+                    if (c < chunks) { const int row = c / ROW_U4; rlds[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < GK; kk++) {
+                const int rr = my_n[(g * GK + kk) * TM];
+                if (__ballot(rr >= 0) != 0ull) {               // wave-uniform; the barriers below are outside
+                    const u32x4* wsrc = wlds + lane;
+                    u32x4 b[S];
+                    const int local = rr - lo;
+                    const bool in_lds = rr >= 0 && local >= 0 && local < cnt;
+                    const u32x4* rsrc_l = rlds + (in_lds ? local : 0) * RS_U4 + half;
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        b[s] = rsrc_l[2 * s];
+                        if (!in_lds) b[s] = zero4;
+                    }
+                    if (!all_in && __ballot(rr >= 0 && !in_lds) != 0ull) {
+                        const unsigned voff = (rr >= 0 && !in_lds) ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
+#pragma unroll
+                        for (int s = 0; s < S; s++) b[s] |= __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < S; s++)
+#pragma unroll
+                        for (int t = 0; t < T; t++)
+                            acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wsrc[(s * T + t) * 64]), __builtin_bit_cast(uint4, b[s]), acc[t]);
+                }
+                if (kk + 1 < GK) {
+                    __syncthreads();                           // every wave is done with this offset's weights
+#pragma unroll
+                    for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wreg[q];
+                    if (kk + 2 < GK) {
+                        const u32x4* w2 = wfrag + (size_t)(g * GK + kk + 2) * TL::GROUP_U4;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) wreg[q] = w2[q * NT + tid];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+
+        const int site = tile0 + wave * 32 + col;
+        if (site < n_live) {
+#pragma unroll
+            for (int t = 0; t < T; t++) {
+                const int co0 = 32 * t + 16 * half;
+                if (co0 >= COUT) continue;
+                const size_t base = (size_t)site * COUT + co0;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) v[q] = acc[t][q];
+                if (bias) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 bb = *reinterpret_cast<const float4*>(bias + co0 + 4 * q4);
+                        v[4 * q4] += bb.x; v[4 * q4 + 1] += bb.y; v[4 * q4 + 2] += bb.z; v[4 * q4 + 3] += bb.w;
+                    }
+                }
+                if (scale) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const float4 sc = *reinterpret_cast<const float4*>(scale + co0 + 4 * q4);
+                        const float4 sh = *reinterpret_cast<const float4*>(shift + co0 + 4 * q4);
+                        v[4 * q4] = v[4 * q4] * sc.x + sh.x; v[4 * q4 + 1] = v[4 * q4 + 1] * sc.y + sh.y;
+                        v[4 * q4 + 2] = v[4 * q4 + 2] * sc.z + sh.z; v[4 * q4 + 3] = v[4 * q4 + 3] * sc.w + sh.w;
+                    }
+                }
+                if (residual) {
+                    const u32x4 r0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base));
+                    const u32x4 r1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(residual + base + 8));
+                    E re[16];
+                    __builtin_memcpy(re, &r0, 16);
+                    __builtin_memcpy(re + 8, &r1, 16);
+#pragma unroll
+                    for (int q = 0; q < 16; q++) v[q] += (float)re[q];
+                }
+                E oe[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) oe[q] = (E)(relu ? fmaxf(v[q], 0.f) : v[q]);
+                u32x4 o0, o1;
+                __builtin_memcpy(&o0, oe, 16);
+                __builtin_memcpy(&o1, oe + 8, 16);
+                __builtin_nontemporal_store(o0, reinterpret_cast<u32x4*>(out + base));
+                __builtin_nontemporal_store(o1, reinterpret_cast<u32x4*>(out + base + 8));
+            }
+        }
+    }
+}
+
 // shapes with a slab form: K = 27 (3 x 3 x 3), LDS = 9 offsets of weights + the rulebook slice + RCAP rows.
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(64, 64, 384)
+#define PVX_SLAB_SHAPES(X) X(64, 64, 384, 0) X(64, 128, 768, 1) X(128, 64, 416, 1) X(128, 128, 368, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
@@ -219,29 +420,28 @@ inline bool slab_enabled() {
 
 inline bool slab_shape(int cin, int cout, int K, int dtype) {
     if (dtype == PVX_F32 || K != 27 || !slab_enabled()) return false;
-#define X(ci, co, rc) if (cin == ci && cout == co) return true;
+#define X(ci, co, rc, st) if (cin == ci && cout == co) return true;
     PVX_SLAB_SHAPES(X)
 #undef X
     return false;
 }
 
-template <typename E, int CIN, int COUT, int RCAP>
+template <typename E, int CIN, int COUT, int RCAP, int STREAM>
 int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n_out, const int* n_out_dev, const float* bias,
                 const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
     const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
-    static int per_cu = 0;
-    if (per_cu == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sparse_conv_slab_kernel<E, CIN, COUT, RCAP>, 512, 0) != hipSuccess || nb < 1)
-            nb = 1;
-        per_cu = nb > 2 ? 2 : nb;
-    }
-    int grid = num_cus() * per_cu;
+    int grid = num_cus();                 // LDS admits one workgroup per CU for every slab shape
     const int tiles = PVX_CDIV(n_out, 256);
     if (grid > tiles) grid = (tiles + 7) / 8 * 8;
-    hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
-                       (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual, relu,
-                       (E*)out);
+    if constexpr (STREAM != 0) {
+        hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                           (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
+                           relu, (E*)out);
+    } else {
+        hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                           (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
+                           relu, (E*)out);
+    }
     return PVX_OK;
 }
