@@ -205,8 +205,8 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
     }
 }
 
-// The same idea for the layers whose weights do not fit LDS nine offsets at a time (>= 16 KiB per offset): ONE offset of weights
-// in LDS, the next one prefetched into registers while the MFMAs of the current one run (two barriers per offset), the row
+// The same idea for the layers whose weights do not fit LDS nine offsets at a time (>= 16 KiB per offset): one offset of weights
+// being read from LDS, the next one written beside it from registers, the one after that in flight (one barrier per offset), the row
 // slab of the dz group loaded once per group as above.  All staging arrays are native vectors (an array of HIP's uint4 struct
 // that is carried around a loop stays an alloca and ends up in scratch or LDS).
 template <typename E, int CIN, int COUT, int RCAP>
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
     constexpr int ROW_U4 = CIN * (int)sizeof(E) / 16, RS_U4 = ROW_U4 + 1;
     constexpr int NW = TL::GROUP_U4 / NT;
     static_assert(TL::GROUP_U4 % NT == 0, "one offset of weights must divide over the workgroup");
-    __shared__ u32x4 wlds[TL::GROUP_U4];
-    __shared__ int nlds[K * TM];
+    __shared__ u32x4 wlds[2 * TL::GROUP_U4];      // two offsets of weights: one being read, one being filled
+    __shared__ int nlds[GK * TM];          // the rulebook rows of the CURRENT dz group (the tile's 27 rows wait in registers)
     __shared__ u32x4 rlds[RCAP * RS_U4];
     __shared__ int g_lo[3], g_hi[3];
     const u32x4* __restrict__ wfrag = reinterpret_cast<const u32x4*>(wfrag_);
@@ -244,29 +244,26 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
         if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
         __syncthreads();
         {
-            int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -1, -1, -1 };
             constexpr int NI = (K * TM + NT - 1) / NT;
-            int tmp[NI];
+            int tmp[NI];                               // first pass: only the row range of each dz group
+            int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -1, -1, -1 };
 #pragma unroll
             for (int q = 0; q < NI; q++) {
                 const int i = q * NT + tid;
                 const int k = i / TM, site = tile0 + (i - k * TM);
                 int v = -1;
-                if (k < K && site < n_live) v = __builtin_nontemporal_load(nbr + (size_t)k * n_out + site);
+                if (k < K && site < n_live) v = nbr[(size_t)k * n_out + site];      // read again per group below: keep it in L2
                 if (v >= n_in) v = -1;
                 tmp[q] = v;
             }
 #pragma unroll
             for (int q = 0; q < NI; q++) {
                 const int i = q * NT + tid;
-                if (i < K * TM) {
-                    nlds[i] = tmp[q];
-                    if (tmp[q] >= 0) {
-                        const int g = (i / TM) / GK;
+                if (i < K * TM && tmp[q] >= 0) {
+                    const int g = (i / TM) / GK;
 #pragma unroll
-                        for (int gg = 0; gg < 3; gg++)
-                            if (g == gg) { lo[gg] = min(lo[gg], tmp[q]); hi[gg] = max(hi[gg], tmp[q]); }
-                    }
+                    for (int gg = 0; gg < 3; gg++)
+                        if (g == gg) { lo[gg] = min(lo[gg], tmp[q]); hi[gg] = max(hi[gg], tmp[q]); }
                 }
             }
 #pragma unroll
@@ -286,44 +283,75 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
             for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
         const int* my_n = nlds + wave * 32 + col;
 
+#pragma unroll 1
         for (int g = 0; g < 3; g++) {
             if (g_hi[g] < 0) continue;
             const int span = g_hi[g] - g_lo[g] + 1;
             const int cnt = span <= RCAP ? span : RCAP;
             const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
             const bool all_in = span <= RCAP;
-            __syncthreads();                               // the previous group is done with wlds / rlds
+            __syncthreads();                               // the previous group is done with wlds / rlds / nlds
+            {
+                constexpr int NG = (GK * TM + NT - 1) / NT;
+                int gt[NG];
+#pragma unroll
+                for (int q = 0; q < NG; q++) {
+                    const int i = q * NT + tid;
+                    const int kk = i / TM, site = tile0 + (i - kk * TM);
+                    int v = -1;
+                    if (kk < GK && site < n_live) v = __builtin_nontemporal_load(nbr + (size_t)(g * GK + kk) * n_out + site);
+                    gt[q] = v >= n_in ? -1 : v;
+                }
+#pragma unroll
+                for (int q = 0; q < NG; q++) if (q * NT + tid < GK * TM) nlds[q * NT + tid] = gt[q];
+            }
             u32x4 wreg[NW];
             {
                 const u32x4* w0 = wfrag + (size_t)(g * GK) * TL::GROUP_U4;
                 u32x4 wt[NW];
 #pragma unroll
                 for (int q = 0; q < NW; q++) wt[q] = w0[q * NT + tid];
-                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT;
-                u32x4 rt[NR];
+                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT, RB = 8;   // rows in batches of RB loads: bounds the live registers
                 const int chunks = cnt * ROW_U4;
-#pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    const int c = q * NT + tid;
-                    rt[q] = zero4;
-                    if (c < chunks) rt[q] = feat_u4[(size_t)lo * ROW_U4 + c];
-                }
 #pragma unroll
                 for (int q = 0; q < NW; q++) wreg[q] = w0[TL::GROUP_U4 + q * NT + tid];      // offset 1 of the group, in flight
 #pragma unroll
-                for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wt[q];
+                for (int q0 = 0; q0 < NR; q0 += RB) {
+                    u32x4 rt[RB];
 #pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    const int c = q * NT + tid;
-                    if (c < chunks) { const int row = c / ROW_U4; rlds[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
+                    for (int q = 0; q < RB; q++) {
+                        const int c = (q0 + q) * NT + tid;
+                        rt[q] = zero4;
+                        if (q0 + q < NR && c < chunks) rt[q] = feat_u4[(size_t)lo * ROW_U4 + c];
+                    }
+                    if (q0 == 0) {
+#pragma unroll
+                        for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wt[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < RB; q++) {
+                        const int c = (q0 + q) * NT + tid;
+                        if (q0 + q < NR && c < chunks) { const int row = c / ROW_U4; rlds[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
+                    }
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int kk = 0; kk < GK; kk++) {
-                const int rr = my_n[(g * GK + kk) * TM];
-                if (__ballot(rr >= 0) != 0ull) {               // wave-uniform; the barriers below are outside
-                    const u32x4* wsrc = wlds + lane;
+                // buffer (kk + 1) & 1 was last read for offset kk - 1 and every wave is past the barrier that closed it: fill it with
+                // offset kk + 1 (in registers since the previous step), then start the loads of offset kk + 2
+                if (kk + 1 < GK) {
+#pragma unroll
+                    for (int q = 0; q < NW; q++) wlds[((kk + 1) & 1) * TL::GROUP_U4 + q * NT + tid] = wreg[q];
+                    if (kk + 2 < GK) {
+                        const u32x4* w2 = wfrag + (size_t)(g * GK + kk + 2) * TL::GROUP_U4;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) wreg[q] = w2[q * NT + tid];
+                    }
+                }
+                const int rr = my_n[kk * TM];
+                if (__ballot(rr >= 0) != 0ull) {               // wave-uniform; the barrier below is outside
+                    const u32x4* wsrc = wlds + (kk & 1) * TL::GROUP_U4 + lane;
                     u32x4 b[S];
                     const int local = rr - lo;
                     const bool in_lds = rr >= 0 && local >= 0 && local < cnt;
@@ -344,17 +372,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
                         for (int t = 0; t < T; t++)
                             acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wsrc[(s * T + t) * 64]), __builtin_bit_cast(uint4, b[s]), acc[t]);
                 }
-                if (kk + 1 < GK) {
-                    __syncthreads();                           // every wave is done with this offset's weights
-#pragma unroll
-                    for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wreg[q];
-                    if (kk + 2 < GK) {
-                        const u32x4* w2 = wfrag + (size_t)(g * GK + kk + 2) * TL::GROUP_U4;
-#pragma unroll
-                        for (int q = 0; q < NW; q++) wreg[q] = w2[q * NT + tid];
-                    }
-                    __syncthreads();
-                }
+                if (kk + 1 < GK) __syncthreads();              // offset kk + 1's weights are in place, offset kk's are free
             }
         }
 
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(64, 64, 384, 0) X(64, 128, 768, 1) X(128, 64, 416, 1) X(128, 128, 368, 1)
+#define PVX_SLAB_SHAPES(X) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
