@@ -149,10 +149,22 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
                         b[s].x |= gth.x; b[s].y |= gth.y; b[s].z |= gth.z; b[s].w |= gth.w;     // out-of-range lanes loaded zeros
                     }
                 }
+                // A fragments of step s + 1 are fetched from LDS while the MFMAs of step s run (left alone, the compiler waits for
+                // each pair of reads right before the two MFMAs that use them)
+                uint4 wa[2][T];
 #pragma unroll
-                for (int s = 0; s < S; s++)
+                for (int t = 0; t < T; t++) wa[0][t] = wsrc[t * 64];
 #pragma unroll
-                    for (int t = 0; t < T; t++) acc[t] = Mfma32<E>::run(wsrc[(s * T + t) * 64], b[s], acc[t]);
+                for (int s = 0; s < S; s++) {
+                    if (s + 1 < S) {
+#pragma unroll
+                        for (int t = 0; t < T; t++) wa[(s + 1) & 1][t] = wsrc[((s + 1) * T + t) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < T; t++) acc[t] = Mfma32<E>::run(wa[s & 1][t], b[s], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
 
@@ -366,11 +378,21 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
 #pragma unroll
                         for (int s = 0; s < S; s++) b[s] |= __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0);
                     }
+                    u32x4 wa[2][T];                            // A fragments of step s + 1 fetched while the MFMAs of step s run
 #pragma unroll
-                    for (int s = 0; s < S; s++)
+                    for (int t = 0; t < T; t++) wa[0][t] = wsrc[t * 64];
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        if (s + 1 < S) {
+#pragma unroll
+                            for (int t = 0; t < T; t++) wa[(s + 1) & 1][t] = wsrc[((s + 1) * T + t) * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int t = 0; t < T; t++)
-                            acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wsrc[(s * T + t) * 64]), __builtin_bit_cast(uint4, b[s]), acc[t]);
+                            acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wa[s & 1][t]), __builtin_bit_cast(uint4, b[s]), acc[t]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 if (kk + 1 < GK) __syncthreads();              // offset kk + 1's weights are in place, offset kk's are free
             }
