@@ -127,42 +127,52 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
                 }
             }
             __syncthreads();
+            // The nine offsets of the group as ONE software pipeline: all nine rulebook entries are read first, the B rows of
+            // offset kk + 1 (LDS reads, plus the gather of lanes outside the window) are issued before the MFMAs of offset kk,
+            // and the A fragments of flat step j + 1 are fetched during the MFMAs of step j, across offset boundaries.  Left to the
+            // compiler, every offset starts with a chain of three dependent LDS round trips and each MFMA pair waits for its reads.
+            int rr[GK];
 #pragma unroll
-            for (int kk = 0; kk < GK; kk++) {
-                const int rr = my_n[(g * GK + kk) * TM];
-                if (__ballot(rr >= 0) == 0ull) continue;   // wave-uniform
-                const uint4* wsrc = wlds + kk * TL::GROUP_U4 + lane;
-                uint4 b[S];
-                const int local = rr - lo;
-                const bool in_lds = rr >= 0 && local >= 0 && local < cnt;
+            for (int kk = 0; kk < GK; kk++) rr[kk] = my_n[(g * GK + kk) * TM];
+            auto load_b = [&](int r, uint4 (&bb)[S]) {
+                const int local = r - lo;
+                const bool in_lds = r >= 0 && local >= 0 && local < cnt;
                 const uint4* rsrc_l = rlds + (in_lds ? local : 0) * RS_U4 + half;
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    b[s] = rsrc_l[2 * s];
-                    if (!in_lds) b[s] = make_uint4(0u, 0u, 0u, 0u);
+                    bb[s] = rsrc_l[2 * s];
+                    if (!in_lds) bb[s] = make_uint4(0u, 0u, 0u, 0u);
                 }
-                if (!all_in && __ballot(rr >= 0 && !in_lds) != 0ull) {      // wave-uniform: somebody's neighbour is outside the window
-                    const unsigned voff = (rr >= 0 && !in_lds) ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
+                if (!all_in && __ballot(r >= 0 && !in_lds) != 0ull) {       // wave-uniform: somebody's neighbour is outside the window
+                    const unsigned voff = (r >= 0 && !in_lds) ? (unsigned)r * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
 #pragma unroll
                     for (int s = 0; s < S; s++) {
                         const uint4 gth = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0));
-                        b[s].x |= gth.x; b[s].y |= gth.y; b[s].z |= gth.z; b[s].w |= gth.w;     // out-of-range lanes loaded zeros
+                        bb[s].x |= gth.x; bb[s].y |= gth.y; bb[s].z |= gth.z; bb[s].w |= gth.w;     // out-of-range lanes loaded zeros
                     }
                 }
-                // A fragments of step s + 1 are fetched from LDS while the MFMAs of step s run (left alone, the compiler waits for
-                // each pair of reads right before the two MFMAs that use them)
-                uint4 wa[2][T];
+            };
+            uint4 bq[2][S];
+            uint4 wa[2][T];
+            load_b(rr[0], bq[0]);
 #pragma unroll
-                for (int t = 0; t < T; t++) wa[0][t] = wsrc[t * 64];
+            for (int t = 0; t < T; t++) wa[0][t] = wlds[t * 64 + lane];
+#pragma unroll
+            for (int kk = 0; kk < GK; kk++) {
+                if (kk + 1 < GK) load_b(rr[kk + 1], bq[(kk + 1) & 1]);
+                const bool on = __ballot(rr[kk] >= 0) != 0ull;              // wave-uniform
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    if (s + 1 < S) {
+                    const int j = kk * S + s;
+                    if (j + 1 < GK * S) {
 #pragma unroll
-                        for (int t = 0; t < T; t++) wa[(s + 1) & 1][t] = wsrc[((s + 1) * T + t) * 64];
+                        for (int t = 0; t < T; t++) wa[(j + 1) & 1][t] = wlds[((j + 1) * T + t) * 64 + lane];   // fragment order is (offset, s, t)
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (on) {
 #pragma unroll
-                    for (int t = 0; t < T; t++) acc[t] = Mfma32<E>::run(wa[s & 1][t], b[s], acc[t]);
+                        for (int t = 0; t < T; t++) acc[t] = Mfma32<E>::run(wa[j & 1][t], bq[kk & 1][s], acc[t]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
+#define PVX_SLAB_SHAPES(X) X(32, 32, 768, 0) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
