@@ -231,8 +231,9 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restri
 // being read from LDS, the next one written beside it from registers, the one after that in flight (one barrier per offset), the row
 // slab of the dz group loaded once per group as above.  All staging arrays are native vectors (an array of HIP's uint4 struct
 // that is carried around a loop stays an alloca and ends up in scratch or LDS).
-template <typename E, int CIN, int COUT, int RCAP>
-__global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
+// WGS workgroups per CU: HIP's second launch bound counts waves per SIMD (a 512-thread workgroup = 2 per SIMD)
+template <typename E, int CIN, int COUT, int RCAP, int WGS>
+__global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
                                                                       const uint4* __restrict__ wfrag_, const int* __restrict__ nbr,
                                                                       int n_out, const int* __restrict__ n_out_dev,
                                                                       const float* __restrict__ bias, const float* __restrict__ scale,
@@ -241,8 +242,9 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
     typedef Tiling32<CIN, COUT> TL;
     constexpr int T = TL::T, S = TL::S, NT = 512, TM = 256, K = 27, GK = 9;
     constexpr int ROW_U4 = CIN * (int)sizeof(E) / 16, RS_U4 = ROW_U4 + 1;
-    constexpr int NW = TL::GROUP_U4 / NT;
-    static_assert(TL::GROUP_U4 % NT == 0, "one offset of weights must divide over the workgroup");
+    constexpr int NW = (TL::GROUP_U4 + NT - 1) / NT;
+    static_assert(TL::GROUP_U4 % NT == 0 || TL::GROUP_U4 < NT, "one offset of weights is spread evenly over the workgroup, or over part of it");
+
     __shared__ u32x4 wlds[2 * TL::GROUP_U4];      // two offsets of weights: one being read, one being filled
     __shared__ int nlds[GK * TM];          // the rulebook rows of the CURRENT dz group (the tile's 27 rows wait in registers)
     __shared__ u32x4 rlds[RCAP * RS_U4];
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
     const u32x4* __restrict__ wfrag = reinterpret_cast<const u32x4*>(wfrag_);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wlane = TL::GROUP_U4 >= NT || tid < TL::GROUP_U4;   // only matters when an offset has fewer than NT 16-byte pieces
     const int col = lane & 31, half = lane >> 5;
     const int n_live = live_rows(n_out, n_out_dev);
     const int ntiles = (n_live + TM - 1) / TM;
@@ -332,11 +335,11 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
                 const u32x4* w0 = wfrag + (size_t)(g * GK) * TL::GROUP_U4;
                 u32x4 wt[NW];
 #pragma unroll
-                for (int q = 0; q < NW; q++) wt[q] = w0[q * NT + tid];
-                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT, RB = 8;   // rows in batches of RB loads: bounds the live registers
+                for (int q = 0; q < NW; q++) wt[q] = wlane ? w0[q * NT + tid] : zero4;
+                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT, RB = WGS > 1 ? 4 : 8;   // rows in batches of RB loads: bounds the live registers
                 const int chunks = cnt * ROW_U4;
 #pragma unroll
-                for (int q = 0; q < NW; q++) wreg[q] = w0[TL::GROUP_U4 + q * NT + tid];      // offset 1 of the group, in flight
+                for (int q = 0; q < NW; q++) wreg[q] = wlane ? w0[TL::GROUP_U4 + q * NT + tid] : zero4;      // offset 1 of the group, in flight
 #pragma unroll
                 for (int q0 = 0; q0 < NR; q0 += RB) {
                     u32x4 rt[RB];
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
                     }
                     if (q0 == 0) {
 #pragma unroll
-                        for (int q = 0; q < NW; q++) wlds[q * NT + tid] = wt[q];
+                        for (int q = 0; q < NW; q++) if (wlane) wlds[q * NT + tid] = wt[q];
                     }
 #pragma unroll
                     for (int q = 0; q < RB; q++) {
@@ -358,36 +361,48 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
                 }
             }
             __syncthreads();
+            // all nine rulebook entries first; the B rows of offset kk + 1 are read (and, outside the window, gathered) before the
+            // MFMAs of offset kk when the registers allow it (rows of <= 64 channels)
+            constexpr bool PF = S <= 4 && WGS == 1;   // at two workgroups per CU (128 VGPRs) the second row buffer spills
+            int rr9[GK];
+#pragma unroll
+            for (int kk = 0; kk < GK; kk++) rr9[kk] = my_n[kk * TM];
+            auto load_b = [&](int r, u32x4 (&bb)[S]) {
+                const int local = r - lo;
+                const bool in_lds = r >= 0 && local >= 0 && local < cnt;
+                const u32x4* rsrc_l = rlds + (in_lds ? local : 0) * RS_U4 + half;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    bb[s] = rsrc_l[2 * s];
+                    if (!in_lds) bb[s] = zero4;
+                }
+                if (!all_in && __ballot(r >= 0 && !in_lds) != 0ull) {
+                    const unsigned voff = (r >= 0 && !in_lds) ? (unsigned)r * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
+#pragma unroll
+                    for (int s = 0; s < S; s++) bb[s] |= __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0);
+                }
+            };
+            u32x4 bq[PF ? 2 : 1][S];
+            if (PF) load_b(rr9[0], bq[0]);
 #pragma unroll
             for (int kk = 0; kk < GK; kk++) {
                 // buffer (kk + 1) & 1 was last read for offset kk - 1 and every wave is past the barrier that closed it: fill it with
                 // offset kk + 1 (in registers since the previous step), then start the loads of offset kk + 2
                 if (kk + 1 < GK) {
 #pragma unroll
-                    for (int q = 0; q < NW; q++) wlds[((kk + 1) & 1) * TL::GROUP_U4 + q * NT + tid] = wreg[q];
+                    for (int q = 0; q < NW; q++) if (wlane) wlds[((kk + 1) & 1) * TL::GROUP_U4 + q * NT + tid] = wreg[q];
                     if (kk + 2 < GK) {
                         const u32x4* w2 = wfrag + (size_t)(g * GK + kk + 2) * TL::GROUP_U4;
 #pragma unroll
-                        for (int q = 0; q < NW; q++) wreg[q] = w2[q * NT + tid];
+                        for (int q = 0; q < NW; q++) wreg[q] = wlane ? w2[q * NT + tid] : zero4;
                     }
                 }
-                const int rr = my_n[kk * TM];
-                if (__ballot(rr >= 0) != 0ull) {               // wave-uniform; the barrier below is outside
+                const int rr = rr9[kk];
+                const bool on = __ballot(rr >= 0) != 0ull;     // wave-uniform; the barrier below is outside
+                if (PF) { if (kk + 1 < GK) load_b(rr9[kk + 1], bq[(kk + 1) & 1]); }
+                else if (on) load_b(rr, bq[0]);
+                if (on) {
                     const u32x4* wsrc = wlds + (kk & 1) * TL::GROUP_U4 + lane;
-                    u32x4 b[S];
-                    const int local = rr - lo;
-                    const bool in_lds = rr >= 0 && local >= 0 && local < cnt;
-                    const u32x4* rsrc_l = rlds + (in_lds ? local : 0) * RS_U4 + half;
-#pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        b[s] = rsrc_l[2 * s];
-                        if (!in_lds) b[s] = zero4;
-                    }
-                    if (!all_in && __ballot(rr >= 0 && !in_lds) != 0ull) {
-                        const unsigned voff = (rr >= 0 && !in_lds) ? (unsigned)rr * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
-#pragma unroll
-                        for (int s = 0; s < S; s++) b[s] |= __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 32 * s, 0, 0);
-                    }
                     u32x4 wa[2][T];                            // A fragments of step s + 1 fetched while the MFMAs of step s run
 #pragma unroll
                     for (int t = 0; t < T; t++) wa[0][t] = wsrc[t * 64];
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int t = 0; t < T; t++)
-                            acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wa[s & 1][t]), __builtin_bit_cast(uint4, b[s]), acc[t]);
+                            acc[t] = Mfma32<E>::run(__builtin_bit_cast(uint4, wa[s & 1][t]), __builtin_bit_cast(uint4, bq[PF ? (kk & 1) : 0][s]), acc[t]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -460,7 +475,7 @@ __global__ __launch_bounds__(512) void sparse_conv_slab_stream_kernel(const E* _
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(32, 32, 768, 0) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
+#define PVX_SLAB_SHAPES(X) X(32, 32, 768, 2) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
@@ -481,11 +496,11 @@ int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n
                 const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
     const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
-    int grid = num_cus();                 // LDS admits one workgroup per CU for every slab shape
+    int grid = num_cus() * (STREAM == 2 ? 2 : 1);      // workgroups per CU that LDS (and the launch bounds) admit
     const int tiles = PVX_CDIV(n_out, 256);
     if (grid > tiles) grid = (tiles + 7) / 8 * 8;
     if constexpr (STREAM != 0) {
-        hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+        hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP, (STREAM == 2 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
                            (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
                            relu, (E*)out);
     } else {
