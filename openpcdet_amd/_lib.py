@@ -23,6 +23,8 @@ c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, cty
 # name -> (restype, argtypes); must list every symbol include/pcdet_mi355.h declares
 SIGNATURES = {
     "pvx_version": (ctypes.c_char_p, []),
+    "pvx_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
+    "pvx_stream_destroy": (c_int, [c_void_p]),
     "pvx_last_hip_error": (c_int, []),
     "pvx_boxes_overlap_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -56,6 +58,7 @@ SIGNATURES = {
     "pvx_scatter_sum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_unique_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
+    "pvx_sparse_conv_set_cu_budget": (c_int, [c_int]),
     "pvx_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
