@@ -8,9 +8,10 @@
 // The CPU algorithm is sequential ("first come": voxel ids in order of first appearance, the first T points
 // of a voxel in input order, cells first seen after max_voxels ids were given are dropped).  The parallel
 // formulation that reproduces it bit-for-bit, independent of thread timing:
-//   1. insert   every in-range point CASes its 64-bit cell key into an open-addressing table in HBM
-//               (linear probing, load factor <= 0.5) and atomicMin's its own index into the slot, so every
-//               occupied slot ends up knowing the FIRST point of its cell;
+//   1. insert   every in-range point CASes the 64-bit word (cell key << 32 | point index) into an open-addressing table
+//               in HBM (linear probing, load factor <= 0.5); a point that finds its cell already there lowers the word
+//               with atomicMin only if it carries a smaller index, so every occupied slot ends up knowing the FIRST
+//               point of its cell at ~1.1 atomics per point;
 //   2. rank     point i is a "first point" iff first[slot(i)] == i.  A wavefront ballot + popcount prefix
 //               (block sums scanned by one workgroup) ranks the first points in input order: that rank IS
 //               the sequential voxel id.  Cells with rank >= max_voxels are exactly the ones the sequential
@@ -49,15 +50,15 @@ __device__ __forceinline__ bool cell_of(float p, float lo, float vs, int g, int&
 }
 
 // Every kernel below runs one frame per blockIdx.y: frame f uses points + f * n * c, its own hash table
-// (keys / first / vid_of_slot + f * table slots), slot_of_point + f * n, block_sums + f * nb, lists + f * max_voxels * T.
+// (table / vid_of_slot + f * table slots), slot_of_point + f * n, block_sums + f * nb, lists + f * max_voxels * T.
 // The single-frame entry points launch with gridDim.y == 1.
 __global__ __launch_bounds__(kBlk) void vox_insert_kernel(const float* __restrict__ pts, int n, int c, VoxGeom g,
-                                                           unsigned long long* keys, int* first, unsigned cap_mask,
+                                                           unsigned long long* table, unsigned cap_mask,
                                                            int* __restrict__ slot_of_point) {
     const int i = blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
     const size_t f = blockIdx.y;
-    pts += f * (size_t)n * c; keys += f * ((size_t)cap_mask + 1); first += f * ((size_t)cap_mask + 1);
+    pts += f * (size_t)n * c; table += f * ((size_t)cap_mask + 1);
     slot_of_point += f * (size_t)n;
     const float* p = pts + (size_t)i * c;
     int cx, cy, cz;
@@ -66,15 +67,21 @@ __global__ __launch_bounds__(kBlk) void vox_insert_kernel(const float* __restric
         return;
     }
     const unsigned long long key = ((unsigned long long)cz * (unsigned long long)g.gy + (unsigned long long)cy) *
-                                   (unsigned long long)g.gx + (unsigned long long)cx;
+                                   (unsigned long long)g.gx + (unsigned long long)cx;      // < 2^32 - 1 (checked on the host)
+    const unsigned long long mine = (key << 32) | (unsigned)i;
     unsigned h = (unsigned)mix64(key) & cap_mask;
     int slot = -1;
     for (unsigned probe = 0; probe <= cap_mask; probe++) {   // bounded: every wave leaves this loop
-        const unsigned long long old = atomicCAS(&keys[h], kEmptyKey, key);
-        if (old == kEmptyKey || old == key) { slot = (int)h; break; }
+        const unsigned long long old = atomicCAS(&table[h], kEmptyKey, mine);
+        if (old == kEmptyKey) { slot = (int)h; break; }
+        if ((old >> 32) == key) {
+            // same cell: the word only ever decreases, so an index above the one seen can never become the minimum
+            if ((unsigned)old > (unsigned)i) atomicMin(&table[h], mine);
+            slot = (int)h;
+            break;
+        }
         h = (h + 1) & cap_mask;
     }
-    if (slot >= 0) atomicMin(&first[slot], i);
     slot_of_point[i] = slot;
 }
 
@@ -97,14 +104,14 @@ __device__ __forceinline__ int block_rank(bool flag, int* wave_sums, int& block_
 }
 
 __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __restrict__ slot_of_point,
-                                                                    const int* __restrict__ first, int n, size_t table_slots,
-                                                                    int* __restrict__ block_sums) {
+                                                                    const unsigned long long* __restrict__ table, int n,
+                                                                    size_t table_slots, int* __restrict__ block_sums) {
     __shared__ int wave_sums[kScanBlk / 64];
     const size_t f = blockIdx.y;
-    slot_of_point += f * (size_t)n; first += f * table_slots; block_sums += f * gridDim.x;
+    slot_of_point += f * (size_t)n; table += f * table_slots; block_sums += f * gridDim.x;
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
-    if (i < n) { const int s = slot_of_point[i]; flag = s >= 0 && first[s] == i; }
+    if (i < n) { const int s = slot_of_point[i]; flag = s >= 0 && (unsigned)table[s] == (unsigned)i; }
     int total;
     block_rank(flag, wave_sums, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -152,8 +159,7 @@ __global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(int* __restri
 }
 
 __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restrict__ slot_of_point,
-                                                               const int* __restrict__ first,
-                                                               const unsigned long long* __restrict__ keys, int n,
+                                                               const unsigned long long* __restrict__ table, int n,
                                                                size_t table_slots, const int* __restrict__ block_offsets, VoxGeom g,
                                                                int max_voxels, int* __restrict__ vid_of_slot,
                                                                int* __restrict__ coords_zyx, int* __restrict__ coords_bzyx,
@@ -161,20 +167,21 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
                                                                int row_capacity) {
     __shared__ int wave_sums[kScanBlk / 64];
     const size_t f = blockIdx.y;
-    slot_of_point += f * (size_t)n; first += f * table_slots; keys += f * table_slots; vid_of_slot += f * table_slots;
+    slot_of_point += f * (size_t)n; table += f * table_slots; vid_of_slot += f * table_slots;
     block_offsets += f * gridDim.x;
     if (coords_zyx) coords_zyx += f * (size_t)max_voxels * 3;
     if (gridDim.y > 1) batch_idx = (int)f;
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
     int s = -1;
-    if (i < n) { s = slot_of_point[i]; flag = s >= 0 && first[s] == i; }
+    unsigned long long word = 0;
+    if (i < n) { s = slot_of_point[i]; if (s >= 0) { word = table[s]; flag = (unsigned)word == (unsigned)i; } }
     int total;
     const int rank = block_offsets[blockIdx.x] + block_rank(flag, wave_sums, total);
     if (flag) {
         vid_of_slot[s] = rank;
         if (rank < max_voxels) {
-            unsigned long long key = keys[s];
+            unsigned long long key = word >> 32;
             const int cx = (int)(key % (unsigned long long)g.gx); key /= (unsigned long long)g.gx;
             const int cy = (int)(key % (unsigned long long)g.gy);
             const int cz = (int)(key / (unsigned long long)g.gy);
@@ -201,10 +208,15 @@ __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict_
     if (point_to_voxel) point_to_voxel[i] = vid;
     if (vid < 0) return;
     int* L = lists + (size_t)vid * T;
-    // already T smaller indices present?  (values only ever decrease, so a stale read only costs work)
-    if (__hip_atomic_load(&L[T - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < i) return;
-    int v = i;
+    // Slot values only ever decrease, so a slot seen holding a smaller index (plain, possibly stale read) holds one for
+    // good and this index belongs behind it: skip those slots instead of paying one atomic round trip each (points mostly
+    // arrive in index order, so a voxel's m-th point would otherwise walk m occupied slots).
+    int t0 = 0;
     for (int t = 0; t < T; t++) {
+        if (L[t] < i) t0 = t + 1; else break;
+    }
+    int v = i;
+    for (int t = t0; t < T; t++) {
         const int old = atomicMin(&L[t], v);
         if (old == kSentinel) break;   // landed in an empty slot
         if (old > v) v = old;          // displaced a larger index: carry it on
@@ -280,20 +292,20 @@ size_t table_capacity(int n) {
 }
 
 struct VoxWorkspace {
-    unsigned long long* keys; int* first; int* lists; int* vid_of_slot; int* slot_of_point; int* block_sums; int* row_bases;
+    unsigned long long* table; int* lists; int* vid_of_slot; int* slot_of_point; int* block_sums; int* row_bases;
 };
 
-// keys are filled with 0xff, first + lists (adjacent on purpose) with 0x7f: two memsets per call
+// the table is filled with 0xff, the lists with 0x7f: two memsets per call
 template <typename C>
 void carve(C& c, int frames, int n, int max_voxels, int T, VoxWorkspace* w) {
     const size_t cap = table_capacity(n), F = (size_t)frames;
     auto k = c.template take<unsigned long long>(F * cap);
-    auto fl = c.template take<int>(F * cap + F * (size_t)max_voxels * T);
+    auto fl = c.template take<int>(F * (size_t)max_voxels * T);
     auto vs = c.template take<int>(F * cap);
     auto sp = c.template take<int>(F * (size_t)(n > 0 ? n : 1));
     auto bs = c.template take<int>(F * (size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
     auto rb = c.template take<int>(F);
-    if (w) { w->keys = (unsigned long long*)k; w->first = (int*)fl; w->lists = fl ? (int*)fl + F * cap : nullptr;
+    if (w) { w->table = (unsigned long long*)k; w->lists = (int*)fl;
              w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp; w->block_sums = (int*)bs; w->row_bases = (int*)rb; }
 }
 
@@ -318,6 +330,8 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     int grid[3];
     int rc = pvx_voxel_grid_size(vsize_xyz, range_xyz, grid);
     if (rc != PVX_OK) return rc;
+    if ((unsigned long long)grid[0] * (unsigned long long)grid[1] * (unsigned long long)grid[2] >= 0xffffffffull)
+        return PVX_ERR_RANGE;   // the cell key shares a 64-bit table word with the point index
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
         PVX_CHECK_HIP(hipMemsetAsync(o.num_voxels, 0, sizeof(int) * frames, st));
@@ -336,20 +350,20 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     carve(cv, frames, n, max_voxels, T, &w);
     if (!cv.ok()) return PVX_ERR_WORKSPACE;
     const size_t cap = table_capacity(n), F = (size_t)frames;
-    PVX_CHECK_HIP(hipMemsetAsync(w.keys, 0xff, F * cap * sizeof(unsigned long long), st));
-    PVX_CHECK_HIP(hipMemsetAsync(w.first, 0x7f, (F * cap + F * (size_t)max_voxels * T) * sizeof(int), st));
+    PVX_CHECK_HIP(hipMemsetAsync(w.table, 0xff, F * cap * sizeof(unsigned long long), st));
+    PVX_CHECK_HIP(hipMemsetAsync(w.lists, 0x7f, F * (size_t)max_voxels * T * sizeof(int), st));
     const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
     const int* row_bases = o.batch ? w.row_bases : o.row_base_dev;
-    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, points, n, c, g, w.keys, w.first,
+    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, points, n, c, g, w.table,
                        (unsigned)(cap - 1), w.slot_of_point);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, n, cap,
+    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
                        w.block_sums);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, frames, max_voxels, o.num_voxels,
                        o.batch ? w.row_bases : nullptr, o.row_capacity, o.batch ? o.row_end_dev : nullptr);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.first, w.keys, n, cap,
+    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
                        w.block_sums, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
                        o.row_capacity);
     PVX_CHECK_LAUNCH();
