@@ -249,12 +249,32 @@ __global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restric
     const int* L = lists + (size_t)v * T;
     float sum = 0.f;
     int cnt = 0;
-    for (int t = 0; t < T; t++) {
-        const int pi = L[t];
-        float val = 0.f;
-        if (pi < n) { val = pts[(size_t)pi * c + ch]; cnt++; }
-        if (voxels) voxels[((size_t)v * T + t) * c + ch] = val;
-        sum += val;
+    constexpr int kFast = 16;
+    if (T <= kFast) {
+        // all list entries, then all point values, are loaded before the (sequential, order-defining) sum: two dependent
+        // round trips per thread instead of 2 T
+        int li[kFast];
+        float val[kFast];
+#pragma unroll
+        for (int t = 0; t < kFast; t++) li[t] = t < T ? L[t] : kSentinel;
+#pragma unroll
+        for (int t = 0; t < kFast; t++) val[t] = li[t] < n ? pts[(size_t)li[t] * c + ch] : 0.f;
+#pragma unroll
+        for (int t = 0; t < kFast; t++) {
+            if (t < T) {
+                if (li[t] < n) cnt++;
+                if (voxels) voxels[((size_t)v * T + t) * c + ch] = val[t];
+                sum += val[t];
+            }
+        }
+    } else {
+        for (int t = 0; t < T; t++) {
+            const int pi = L[t];
+            float val = 0.f;
+            if (pi < n) { val = pts[(size_t)pi * c + ch]; cnt++; }
+            if (voxels) voxels[((size_t)v * T + t) * c + ch] = val;
+            sum += val;
+        }
     }
     if (ch == 0 && num_per_voxel) num_per_voxel[v] = cnt;
     if (mean && row < row_capacity) {
