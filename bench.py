@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--no-vox-ahead", action="store_true",
+                    help="voxelize each batch inside its own step instead of one step ahead, beside the previous batch's rulebooks")
     ap.add_argument("--geometry-cus", type=int, default=0,
                     help="CUs reserved for the geometry / NMS streams (CU-masked streams; 0 = shared CUs, priority streams)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
@@ -189,18 +191,26 @@ def main():
             hot_path()
         note("graph captured")
 
+    vox_ahead = pipelined and not args.no_vox_ahead
+    vox_stream = torch.cuda.Stream(device=dev) if vox_ahead else None
+
     def step(i):
         if pipelined:
             plan = eng if i % 2 == 0 else eng2
             cur = torch.cuda.current_stream(dev)
-            geo = plan.geometry_stream()
-            with torch.cuda.stream(geo):
-                geo.wait_event(plan._done)      # the plan's previous batch has left these buffers
-                load_points(i, plan)
+            if vox_ahead:
+                # batch i was voxelized during step i-1; batch i+1 is voxelized now, on its own stream, beside batch i's rulebooks
+                nxt = eng2 if i % 2 == 0 else eng
+                nxt.voxelize_ahead(vox_stream, load=lambda: load_points(i + 1, nxt))
+            else:
+                geo = plan.geometry_stream()
+                with torch.cuda.stream(geo):
+                    geo.wait_event(plan._done)      # the plan's previous batch has left these buffers
+                    load_points(i, plan)
             with torch.cuda.stream(nms_stream):   # its inputs are loaded on its own stream: nothing to wait for
                 load_boxes(i)
                 result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
-            plan.forward(overlap=True, pipelined=True)
+            plan.forward(overlap=True, pipelined=True, prevoxelized=vox_ahead)
             cur.wait_stream(nms_stream)
             return
         load(i)
@@ -220,6 +230,8 @@ def main():
         nms_stream = geo_stream
     conv_stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(conv_stream):
+        if vox_ahead:      # the first batch's voxelization; from then on every step voxelizes the batch after its own
+            eng.voxelize_ahead(vox_stream, load=lambda: load_points(0, eng))
         for i in range(args.warmup):
             step(i)
         # barrier + device sync on both sides, MAX over ranks (openpcdet_amd/dist.py; tests/test_dist_gloo.py runs it at world 2)
@@ -327,7 +339,7 @@ def main():
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
                        "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else 3, "plans_in_flight": 2 if pipelined else 1,
-                       "geometry_cus": args.geometry_cus if pipelined else 0, "rows_per_level": rows},
+                       "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "rows_per_level": rows},
             "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
                        "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},

@@ -310,7 +310,23 @@ class HotPathEngine:
 
     _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
 
-    def forward(self, overlap=True, pipelined=False):
+    def voxelize_ahead(self, stream, load=None):
+        """Voxelize the NEXT batch of this plan on `stream` while another plan's rulebooks are being built: waits for this
+        plan's previous forward (whose convs read the level-0 rows and counts), calls `load()` (which copies the frames into
+        `self.points` on `stream`), voxelizes, and records the event that `forward(prevoxelized=True)` waits for.  The
+        voxelizer is bound by atomic round trips and the rulebook kernels by bandwidth, so the two overlap well."""
+        with torch.cuda.device(self.device):
+            self._geo_stream()
+            if getattr(self, "_vox_done", None) is None:
+                self._vox_done = torch.cuda.Event()
+            with torch.cuda.stream(stream):
+                stream.wait_event(self._done)
+                if load is not None:
+                    load()
+                self.voxelize(stream.cuda_stream)
+                self._vox_done.record(stream)
+
+    def forward(self, overlap=True, pipelined=False, prevoxelized=False):
         """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
         static buffer) or None.  No host synchronisation.
 
@@ -321,7 +337,9 @@ class HotPathEngine:
         geometry kernels use.
         pipelined: for a serving loop that alternates TWO plans (frames i, i+2, ... on one; i+1, i+3, ... on the other): the
         geometry stream then does not wait for the main stream (so the geometry of frame i+1 runs beside the convolutions of
-        frame i) but only for this plan's own previous forward; the caller loads `points` on `geometry_stream()`."""
+        frame i) but only for this plan's own previous forward; the caller loads `points` on `geometry_stream()`.
+        prevoxelized: `voxelize_ahead()` has already voxelized this batch (on a third stream, beside the previous batch's
+        rulebook kernels); the geometry stream only waits for it."""
         with torch.cuda.device(self.device):
             main = torch.cuda.current_stream(self.device)
             if not overlap:
@@ -330,12 +348,15 @@ class HotPathEngine:
                 self.backbone(st)
             else:
                 geo = self._geo_stream()
-                if pipelined:
-                    geo.wait_event(self._done)            # the convs of this plan's previous batch read the rulebooks
-                else:
-                    geo.wait_stream(main)                 # the frames were loaded on the main stream
                 g, m = geo.cuda_stream, main.cuda_stream
-                self.voxelize(g)
+                if prevoxelized:
+                    geo.wait_event(self._vox_done)        # voxelize_ahead() ran after this plan's previous forward
+                else:
+                    if pipelined:
+                        geo.wait_event(self._done)        # the convs of this plan's previous batch read the rulebooks
+                    else:
+                        geo.wait_stream(main)             # the frames were loaded on the main stream
+                    self.voxelize(g)
                 pending = self._geo_events[0]
                 pending.record(geo)
                 i = 1
