@@ -338,7 +338,7 @@ def main():
             "config": {"workload": "CenterPoint nuScenes 10-sweep 300k pts/frame, 0.075 m voxels, VoxelResBackBone8x, "
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
-                       "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else 3, "plans_in_flight": 2 if pipelined else 1,
+                       "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
                        "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "rows_per_level": rows},
             "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
