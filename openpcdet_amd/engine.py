@@ -488,3 +488,12 @@ def cu_partition_streams(device, geometry_cus, total_cus=None):
             streams.append(torch.cuda.ExternalStream(out.value, device=device))
     _lib.check(L.pvx_sparse_conv_set_cu_budget(total - g), "pvx_sparse_conv_set_cu_budget")
     return streams[0], streams[1]
+
+
+def release_cu_partition(conv_stream, geometry_stream):
+    """destroy the two streams of `cu_partition_streams` (after synchronising them) and give the convs the whole chip back"""
+    L = _lib.lib()
+    for st in (conv_stream, geometry_stream):
+        st.synchronize()
+        _lib.check(L.pvx_stream_destroy(ctypes.c_void_p(st.cuda_stream)), "pvx_stream_destroy")
+    _lib.check(L.pvx_sparse_conv_set_cu_budget(0), "pvx_sparse_conv_set_cu_budget")

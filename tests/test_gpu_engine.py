@@ -261,3 +261,59 @@ def test_engine_sorted_input_equals_first_come(cuda_device):
         assert torch.equal(st_s[i][0], st_f[i][0]), "stage %d coordinates" % i
         assert torch.equal(st_s[i][1], st_f[i][1]), "stage %d features" % i
     assert torch.equal(bev_s, bev_f)
+
+
+def test_voxelize_ahead_cu_budget_and_masked_streams(cuda_device):
+    """the serving-loop knobs change scheduling only: voxelize-ahead on a third stream, a conv CU budget and CU-masked
+    streams all give the bits of the plain forward"""
+    from openpcdet_amd import _lib
+    L = _lib.lib()
+    cfg = SMALL
+    frames_a = [synth.config_cloud("nuscenes_centerpoint", seed, n_points=20000) for seed in (51, 52)]
+    frames_b = [synth.config_cloud("nuscenes_centerpoint", seed, n_points=15000) for seed in (53, 54)]
+    net = make_backbone(backbones.VoxelResBackBone8x, cfg, 13, cuda_device)
+    eng = engine.HotPathEngine(net, 2, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], 20000,
+                               dtype=torch.bfloat16, device=cuda_device)
+
+    def to_dev(fr):
+        return [torch.from_numpy(f).to(cuda_device) for f in fr]
+
+    want = []
+    for fr in (frames_a, frames_b):
+        eng.load_points(to_dev(fr))
+        want.append(eng.forward(overlap=False).clone())
+    torch.cuda.synchronize()
+    # 1. voxelize-ahead: batch b is voxelized on its own stream before forward(prevoxelized=True) of the same plan
+    side = torch.cuda.Stream(device=cuda_device)
+    for fr, w in zip((frames_a, frames_b), want):
+        dev_frames = to_dev(fr)
+        torch.cuda.synchronize()
+        eng.voxelize_ahead(side, load=lambda: eng.load_points(dev_frames))
+        got = eng.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, w)
+    # 2. conv CU budget: fewer, longer-running workgroups, same sums
+    try:
+        assert L.pvx_sparse_conv_set_cu_budget(64) == 0
+        eng.load_points(to_dev(frames_a))
+        got = eng.forward(overlap=False).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[0])
+        assert L.pvx_sparse_conv_set_cu_budget(-1) != 0
+    finally:
+        L.pvx_sparse_conv_set_cu_budget(0)
+    # 3. CU-masked streams (conv on one CU set, geometry on the rest); the helper also sets the budget
+    try:
+        conv_s, geo_s = engine.cu_partition_streams(cuda_device, 64)
+        eng.use_geometry_stream(geo_s)
+        conv_s.wait_stream(torch.cuda.current_stream(cuda_device))
+        with torch.cuda.stream(conv_s):
+            eng.load_points(to_dev(frames_b))
+            got = eng.forward(overlap=True).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want[1])
+        eng.use_geometry_stream(torch.cuda.Stream(device=cuda_device))
+        engine.release_cu_partition(conv_s, geo_s)
+    finally:
+        L.pvx_sparse_conv_set_cu_budget(0)
+    assert L.pvx_stream_create_cu_mask(None, 0, None) != 0
