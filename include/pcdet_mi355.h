@@ -323,6 +323,22 @@ int pvx_sparse_conv_wgrad(const void* feat_in, int n_in, int cin, const void* gr
 int pvx_sparse_to_dense(const void* feat, const int* coords, int n, const int* n_dev, int c, int dtype, int batch,
                         const int* shape_dhw, void* out, void* stream);
 
+/* ---- CenterPoint head decode ------------------------------------------------------------
+ * Per frame: the K largest values of heatmap[b] ([C, H, W], already sigmoid-ed) in descending order (equal values: lower
+ * flat index c*H*W + y*W + x first), each decoded to x, y, z, dx, dy, dz, heading[, vx, vy] with the reference's float32
+ * operation order, masked by post_center_limit_range (x, y, z within [lim[0:3], lim[3:6]]) and, when score_thresh is not
+ * NULL, by score > *score_thresh; survivors are written in score order to boxes[b, 0:counts[b]] ([B, K, 7] or [B, K, 9]
+ * with vel), scores[b, :], labels[b, :] (class index inside this head).  center [B,2,H,W], center_z [B,1,H,W],
+ * dim [B,3,H,W] (already exp-ed), rot_cos / rot_sin: one [H,W] plane per frame, rot_batch_stride elements apart (2*H*W
+ * when both are channel views of one [B,2,H,W] tensor), vel [B,2,H,W] or NULL.  K <= 1024.
+ * Replaces centernet_utils.py:163-254 (_topk, _transpose_and_gather_feat, decode_bbox_from_heatmap) as called from
+ * center_head.py:343-352; circle_nms and the iou branch are not taken by the reference's configs and are not built. */
+int pvx_center_decode(const float* heatmap, const float* center, const float* center_z, const float* dim,
+                      const float* rot_cos, const float* rot_sin, long long rot_batch_stride, const float* vel, int batch,
+                      int num_class, int h, int w, int k, float feature_map_stride, const float* voxel_size_xy,
+                      const float* range_min_xy, const float* post_center_limit_range, const float* score_thresh,
+                      float* boxes, float* scores, int* labels, int* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

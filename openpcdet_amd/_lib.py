@@ -59,6 +59,8 @@ SIGNATURES = {
     "pvx_unique_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
     "pvx_sparse_conv_set_cu_budget": (c_int, [c_int]),
+    "pvx_center_decode": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pvx_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
