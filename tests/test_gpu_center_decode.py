@@ -67,3 +67,58 @@ def test_decode_ties_short_frames_and_empty_results(cuda_device):
     t = torch.zeros((1, 1, 4, 4), device=cuda_device)
     with pytest.raises(NotImplementedError):
         centernet_utils.decode_bbox_from_heatmap(t, t, t, t, t, t, circle_nms=True, post_center_limit_range=[0] * 6)
+
+
+def test_center_head_post_processing_all_heads_one_nms(cuda_device):
+    """generate_predicted_boxes (6 heads x B frames: one decode launch per head, one batched NMS) against the oracle decode +
+    the oracle NMS composed as center_head.py:332-389 composes them"""
+    from openpcdet_amd import center_head_post
+    from oracle import loader
+    r = np.random.default_rng(3)
+    B, H, W, K = 2, 64, 60, 200
+    classes = [1, 2, 2, 1, 2, 2]
+    mapping, base = [], 0
+    for c in classes:
+        mapping.append(torch.arange(base, base + c, dtype=torch.int64)); base += c
+    cfg = dict(MAX_OBJ_PER_SAMPLE=K, SCORE_THRESH=0.1, POST_CENTER_LIMIT_RANGE=[-61.2, -61.2, -10.0, 61.2, 61.2, 10.0],
+               NMS_CONFIG=dict(NMS_TYPE="nms_gpu", NMS_THRESH=0.2, NMS_PRE_MAXSIZE=150, NMS_POST_MAXSIZE=83))
+    pcr, vs, stride = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [0.1, 0.1, 0.2], 8
+    pred = []
+    for c in classes:
+        # clustered peaks so that the NMS has something to suppress
+        hm = r.normal(-4.0, 1.0, (B, c, H, W))
+        for _ in range(25):
+            b, k, y, x = r.integers(B), r.integers(c), r.integers(2, H - 2), r.integers(2, W - 2)
+            hm[b, k, y - 1:y + 2, x - 1:x + 2] += r.uniform(3.0, 6.0)
+        pred.append(dict(hm=hm.astype(np.float32), center=r.uniform(0, 1, (B, 2, H, W)).astype(np.float32),
+                         center_z=r.uniform(-2, 1, (B, 1, H, W)).astype(np.float32),
+                         dim=r.normal(1.0, 0.3, (B, 3, H, W)).astype(np.float32),
+                         rot=r.normal(size=(B, 2, H, W)).astype(np.float32), vel=r.normal(size=(B, 2, H, W)).astype(np.float32)))
+    dev_pred = [{k: torch.from_numpy(v).to(cuda_device) for k, v in p.items()} for p in pred]
+    got = center_head_post.generate_predicted_boxes(B, dev_pred, mapping, pcr, vs, stride, cfg, has_vel=True)
+    assert len(got) == B
+    want = [dict(b=[], s=[], l=[]) for _ in range(B)]
+    tight = False
+    for h, p in enumerate(dev_pred):
+        hm = p["hm"].sigmoid().cpu().numpy(); dim = p["dim"].exp().cpu().numpy()          # the activations the device path used
+        dec = center_decode.decode_bbox_from_heatmap(hm, pred[h]["rot"][:, 0:1], pred[h]["rot"][:, 1:2], pred[h]["center"],
+                                                     pred[h]["center_z"], dim, pcr, vs, stride, vel=pred[h]["vel"], K=K,
+                                                     score_thresh=cfg["SCORE_THRESH"],
+                                                     post_center_limit_range=cfg["POST_CENTER_LIMIT_RANGE"])
+        for b in range(B):
+            bx, sc, lb = dec[b]["pred_boxes"][:150], dec[b]["pred_scores"][:150], dec[b]["pred_labels"][:150]
+            keep, margin = loader.nms(bx[:, :7], 0.2) if len(bx) else (np.zeros(0, np.int64), 1.0)
+            tight |= margin < 1e-4
+            keep = keep[:83]
+            want[b]["b"].append(bx[keep]); want[b]["s"].append(sc[keep]); want[b]["l"].append(mapping[h].numpy()[lb[keep]] + 1)
+    assert not tight, "an IoU sits within 1e-4 of the threshold: pick another seed"
+    total = 0
+    for b in range(B):
+        wb, wsc, wl = np.concatenate(want[b]["b"]), np.concatenate(want[b]["s"]), np.concatenate(want[b]["l"])
+        total += len(wsc)
+        assert np.array_equal(got[b]["pred_scores"].cpu().numpy(), wsc)
+        assert np.array_equal(got[b]["pred_labels"].cpu().numpy(), wl)
+        gb = got[b]["pred_boxes"].cpu().numpy()
+        assert np.array_equal(gb[:, :6], wb[:, :6]) and np.array_equal(gb[:, 7:], wb[:, 7:])
+        assert np.allclose(gb[:, 6], wb[:, 6], rtol=0, atol=1e-6)
+    assert total > 50            # the case is not vacuous
