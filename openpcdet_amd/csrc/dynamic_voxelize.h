@@ -166,7 +166,7 @@ extern "C" int pvx_dynamic_voxelize(const float* points, int n, const int* n_dev
         hipLaunchKernelGGL(dyn_setbits_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, points, n, n_dev, row_floats, g, s, idx);
         PVX_CHECK_LAUNCH();
     }
-    int rc = scan_index(idx, words, block_sums, num_voxels, st);
+    int rc = scan_index(idx, words, block_sums, nullptr, num_voxels, st);
     if (rc != PVX_OK) return rc;
     if (n > 0) {
         hipLaunchKernelGGL(dyn_assign_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, points, n, n_dev, row_floats, g, s, idx,

@@ -65,8 +65,11 @@ __device__ __forceinline__ int live_rows(int n, const int* __restrict__ n_dev) {
     return v < n ? v : n;
 }
 
+// flags (optional): one int per kScanBlock words, set when the block holds a bit, so that the count / prefix passes can skip
+// the empty stretches of a sparse grid (the level-0 grid of a LiDAR frame is > 99.8 % empty)
 __global__ __launch_bounds__(kBlk) void idx_setbits_kernel(const int* __restrict__ coords, int n_cap,
-                                                            const int* __restrict__ n_dev, Dims s, IndexEntry* idx) {
+                                                            const int* __restrict__ n_dev, Dims s, IndexEntry* idx,
+                                                            int* __restrict__ flags) {
     const int n = live_rows(n_cap, n_dev);
     const int i = blockIdx.x * kBlk + threadIdx.x;
     if (i >= n) return;
@@ -74,11 +77,16 @@ __global__ __launch_bounds__(kBlk) void idx_setbits_kernel(const int* __restrict
     if (c.x < 0 || c.x >= s.b || c.y < 0 || c.y >= s.d || c.z < 0 || c.z >= s.h || c.w < 0 || c.w >= s.w) return;
     const long long key = lin_key(c.x, c.y, c.z, c.w, s);
     atomicOr(&idx[key >> 6].bits, 1ull << (key & 63));
+    if (flags) flags[(key >> 6) / pvx::kScanBlock] = 1;      // every writer stores the same value
 }
 
 __global__ __launch_bounds__(pvx::kScanBlock) void idx_count_kernel(const IndexEntry* __restrict__ idx, long long words,
-                                                                     int* __restrict__ block_sums) {
+                                                                     int* __restrict__ block_sums, const int* __restrict__ flags) {
     __shared__ int wave_sums[pvx::kScanBlock / 64];
+    if (flags && flags[blockIdx.x] == 0) {                   // whole workgroup: no barrier is skipped by part of it
+        if (threadIdx.x == 0) block_sums[blockIdx.x] = 0;
+        return;
+    }
     const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
     const int v = w < words ? __popcll(idx[w].bits) : 0;
     int total;
@@ -87,8 +95,10 @@ __global__ __launch_bounds__(pvx::kScanBlock) void idx_count_kernel(const IndexE
 }
 
 __global__ __launch_bounds__(pvx::kScanBlock) void idx_prefix_kernel(IndexEntry* __restrict__ idx, long long words,
-                                                                      const int* __restrict__ block_offsets) {
+                                                                      const int* __restrict__ block_offsets,
+                                                                      const int* __restrict__ flags) {
     __shared__ int wave_sums[pvx::kScanBlock / 64];
+    if (flags && flags[blockIdx.x] == 0) return;             // no bit in this block: its prefixes are never read
     const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
     const int v = w < words ? __popcll(idx[w].bits) : 0;
     int total;
@@ -273,13 +283,13 @@ bool dims_ok(const Dims& s, long long* words) {
 
 constexpr long long kMaxWords = 1ll << 28;   // 16 Gi cells, 4 GiB of index: beyond this use a coarser partition
 
-int scan_index(IndexEntry* idx, long long words, int* block_sums, int* total_dev, hipStream_t st) {
+int scan_index(IndexEntry* idx, long long words, int* block_sums, const int* flags, int* total_dev, hipStream_t st) {
     const int nb = (int)PVX_CDIV(words, (long long)pvx::kScanBlock);
-    hipLaunchKernelGGL(idx_count_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums);
+    hipLaunchKernelGGL(idx_count_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums, flags);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(pvx::scan_block_sums_kernel, dim3(1), dim3(pvx::kScanBlock), 0, st, block_sums, nb, -1, total_dev);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(idx_prefix_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums);
+    hipLaunchKernelGGL(idx_prefix_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums, flags);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }
@@ -315,7 +325,8 @@ extern "C" size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw
     long long words;
     if (!dims_ok(s, &words) || words > kMaxWords) return 256;
     PvxSizer z;
-    z.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
+    z.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));      // block sums
+    z.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));      // block flags (pvx_site_index_build)
     return z.total();
 }
 
@@ -329,15 +340,18 @@ extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, 
     if (words > kMaxWords) return PVX_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
     PvxCarver cv(workspace, workspace_bytes);
-    int* block_sums = cv.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
+    const size_t nblocks = (size_t)PVX_CDIV(words, (long long)pvx::kScanBlock);
+    int* block_sums = cv.take<int>(nblocks);
+    int* flags = cv.take<int>(nblocks);
     if (!cv.ok()) return PVX_ERR_WORKSPACE;
     IndexEntry* idx = (IndexEntry*)index;
     PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
+    PVX_CHECK_HIP(hipMemsetAsync(flags, 0, nblocks * sizeof(int), st));
     if (n > 0) {
-        hipLaunchKernelGGL(idx_setbits_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx);
+        hipLaunchKernelGGL(idx_setbits_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx, flags);
         PVX_CHECK_LAUNCH();
     }
-    int rc = scan_index(idx, words, block_sums, n_unique, st);
+    int rc = scan_index(idx, words, block_sums, flags, n_unique, st);
     if (rc != PVX_OK) return rc;
     if (perm && n > 0) {
         hipLaunchKernelGGL(idx_perm_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx, perm);
@@ -392,7 +406,7 @@ extern "C" int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_i
         hipLaunchKernelGGL(conv_out_setbits_kernel, dim3(PVX_CDIV(n_in, kBlk)), dim3(kBlk), 0, st, coords_in, n_in, n_in_dev, g, idx);
         PVX_CHECK_LAUNCH();
     }
-    return scan_index(idx, words, block_sums, n_out, st);
+    return scan_index(idx, words, block_sums, nullptr, n_out, st);
 }
 
 extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
