@@ -339,6 +339,19 @@ int pvx_center_decode(const float* heatmap, const float* center, const float* ce
                       const float* range_min_xy, const float* post_center_limit_range, const float* score_thresh,
                       float* boxes, float* scores, int* labels, int* counts, void* stream);
 
+/* The same selection + decode for a SPARSE head (VoxelNeXt): frame b owns rows [row_begin[b], row_begin[b+1]) of
+ * obj [N, C] (scores, already sigmoid-ed; rows of a frame contiguous), flat index c * rows + r; center [N,2],
+ * center_z [N,1], dim [N,3] (exp-ed), rot_cos / rot_sin [N,1], vel [N,2] or NULL, spatial [N, spatial_dims] int32 voxel
+ * indices ending in (y, x); stride_rows [N] (one feature-map stride per row) or NULL for the scalar feature_map_stride.
+ * x = ((x_idx + center_x) * stride) * voxel_x + range_min_x, likewise y.  Outputs as pvx_center_decode.
+ * Replaces centernet_utils.py:256-367 (_topk_1d with nuscenes=True, gather_feat_idx, decode_bbox_from_voxels_nuscenes)
+ * as called from voxelnext_head.py:generate_predicted_boxes. */
+int pvx_voxel_decode(const float* obj, const int* row_begin, const int* spatial, int spatial_dims, const float* center,
+                     const float* center_z, const float* dim, const float* rot_cos, const float* rot_sin, const float* vel,
+                     const float* stride_rows, int batch, int num_class, int k, float feature_map_stride,
+                     const float* voxel_size_xy, const float* range_min_xy, const float* post_center_limit_range,
+                     const float* score_thresh, float* boxes, float* scores, int* labels, int* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ SIGNATURES = {
     "pvx_sparse_conv_set_cu_budget": (c_int, [c_int]),
     "pvx_center_decode": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pvx_voxel_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, ctypes.c_float] +
+                         [c_void_p] * 9),
     "pvx_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),

@@ -51,8 +51,12 @@ struct DecodeArgs {
     float score_thresh;
     int has_thresh;
     float* boxes; float* scores; int* labels; int* counts;
+    // sparse (VoxelNeXt) form: the frame's scores are rows [row_begin[b], row_begin[b + 1]) of obj [N, C], flat index
+    // c * rows + r; regression rows are [N, ch]; spatial [N, sd] holds (.., y, x); stride_rows (optional) one stride per row
+    const int* row_begin; const int* spatial; int sd; const float* stride_rows;
 };
 
+template <bool SPARSE>
 __global__ __launch_bounds__(kThreads) void center_decode_kernel(DecodeArgs a) {
 #pragma clang fp contract(off)
     __shared__ int hist[2048];
@@ -61,10 +65,17 @@ __global__ __launch_bounds__(kThreads) void center_decode_kernel(DecodeArgs a) {
     __shared__ int sh_bin, sh_need, sh_count, sh_eq_taken;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    const int hw = a.h * a.w;
+    const int row0 = SPARSE ? a.row_begin[b] : 0;
+    const int hw = SPARSE ? a.row_begin[b + 1] - row0 : a.h * a.w;      // cells (dense) or voxel rows (sparse) of this frame
     const int n = a.num_class * hw;
-    const float* hm = a.heatmap + (size_t)b * n;
+    const float* hm = SPARSE ? a.heatmap : a.heatmap + (size_t)b * n;
     const int K = a.k < n ? a.k : n;
+    // score of flat index i = c * hw + r
+    auto score_at = [&](int i) -> float {
+        if (!SPARSE) return hm[i];
+        const int c = i / hw, r = i - c * hw;
+        return hm[(size_t)(row0 + r) * a.num_class + c];
+    };
 
     // ---- 1. the K-th largest order_bits value ------------------------------------------------------------------------
     unsigned prefix = 0;          // bits decided so far (aligned to the top)
@@ -77,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void center_decode_kernel(DecodeArgs a) {
         __syncthreads();
         const int hi_shift = shift + widths[p];                 // bits above this digit
         for (int i = tid; i < n; i += kThreads) {
-            const unsigned key = order_bits(hm[i]);
+            const unsigned key = order_bits(score_at(i));
             if (p == 0 || (key >> hi_shift) == (prefix >> hi_shift)) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1);
         }
         __syncthreads();
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void center_decode_kernel(DecodeArgs a) {
         const int i = base + tid;
         unsigned key = 0;
         bool gt = false, eq = false;
-        if (i < n) { key = order_bits(hm[i]); gt = key > kth; eq = key == kth; }
+        if (i < n) { key = order_bits(score_at(i)); gt = key > kth; eq = key == kth; }
         if (gt) cand[atomicAdd(&sh_count, 1)] = ((unsigned long long)key << 32) | (0xffffffffu - (unsigned)i);
         if (__syncthreads_or(eq)) {
             const int rank = block_inclusive_scan(eq ? 1 : 0, scan) - 1;      // among this chunk's equals, in index order
@@ -138,20 +149,33 @@ __global__ __launch_bounds__(kThreads) void center_decode_kernel(DecodeArgs a) {
     if (tid < K) {
         const unsigned long long c = cand[tid];
         const int idx = (int)(0xffffffffu - (unsigned)(c & 0xffffffffull));
-        score = hm[idx];
+        score = score_at(idx);
         label = idx / hw;
         const int pix = idx - label * hw;
-        const int yi = pix / a.w, xi = pix - yi * a.w;
-        const size_t f2 = (size_t)b * 2 * hw, f1 = (size_t)b * hw, f3 = (size_t)b * 3 * hw;
-        float xs = (float)xi + a.center[f2 + pix];
-        float ys = (float)yi + a.center[f2 + hw + pix];
-        xs = xs * a.stride * a.voxel_x + a.range_x;               // (xs * stride) * voxel + range, each step rounded
-        ys = ys * a.stride * a.voxel_y + a.range_y;
-        box[0] = xs; box[1] = ys; box[2] = a.center_z[f1 + pix];
-        box[3] = a.dim[f3 + pix]; box[4] = a.dim[f3 + hw + pix]; box[5] = a.dim[f3 + 2 * hw + pix];
-        const size_t fr = (size_t)b * (size_t)a.rot_batch_stride;
-        box[6] = atan2f(a.rot_sin[fr + pix], a.rot_cos[fr + pix]);
-        if (a.vel) { box[7] = a.vel[f2 + pix]; box[8] = a.vel[f2 + hw + pix]; }
+        if (!SPARSE) {
+            const int yi = pix / a.w, xi = pix - yi * a.w;
+            const size_t f2 = (size_t)b * 2 * hw, f1 = (size_t)b * hw, f3 = (size_t)b * 3 * hw;
+            float xs = (float)xi + a.center[f2 + pix];
+            float ys = (float)yi + a.center[f2 + hw + pix];
+            xs = xs * a.stride * a.voxel_x + a.range_x;               // (xs * stride) * voxel + range, each step rounded
+            ys = ys * a.stride * a.voxel_y + a.range_y;
+            box[0] = xs; box[1] = ys; box[2] = a.center_z[f1 + pix];
+            box[3] = a.dim[f3 + pix]; box[4] = a.dim[f3 + hw + pix]; box[5] = a.dim[f3 + 2 * hw + pix];
+            const size_t fr = (size_t)b * (size_t)a.rot_batch_stride;
+            box[6] = atan2f(a.rot_sin[fr + pix], a.rot_cos[fr + pix]);
+            if (a.vel) { box[7] = a.vel[f2 + pix]; box[8] = a.vel[f2 + hw + pix]; }
+        } else {
+            const size_t row = (size_t)row0 + pix;
+            const float st = a.stride_rows ? a.stride_rows[row] : a.stride;
+            float xs = (float)a.spatial[row * a.sd + a.sd - 1] + a.center[row * 2];        // centernet_utils.py:324-325
+            float ys = (float)a.spatial[row * a.sd + a.sd - 2] + a.center[row * 2 + 1];
+            xs = xs * st * a.voxel_x + a.range_x;
+            ys = ys * st * a.voxel_y + a.range_y;
+            box[0] = xs; box[1] = ys; box[2] = a.center_z[row];
+            box[3] = a.dim[row * 3]; box[4] = a.dim[row * 3 + 1]; box[5] = a.dim[row * 3 + 2];
+            box[6] = atan2f(a.rot_sin[row], a.rot_cos[row]);
+            if (a.vel) { box[7] = a.vel[row * 2]; box[8] = a.vel[row * 2 + 1]; }
+        }
         valid = box[0] >= a.lim[0] && box[1] >= a.lim[1] && box[2] >= a.lim[2] &&
                 box[0] <= a.lim[3] && box[1] <= a.lim[4] && box[2] <= a.lim[5];
         if (a.has_thresh) valid = valid && score > a.score_thresh;
@@ -190,7 +214,36 @@ extern "C" int pvx_center_decode(const float* heatmap, const float* center, cons
     a.has_thresh = score_thresh ? 1 : 0;
     a.score_thresh = score_thresh ? *score_thresh : 0.f;
     a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts;
-    hipLaunchKernelGGL(center_decode_kernel, dim3(batch), dim3(kThreads), 0, (hipStream_t)stream, a);
+    a.row_begin = nullptr; a.spatial = nullptr; a.sd = 0; a.stride_rows = nullptr;
+    hipLaunchKernelGGL(center_decode_kernel<false>, dim3(batch), dim3(kThreads), 0, (hipStream_t)stream, a);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_voxel_decode(const float* obj, const int* row_begin, const int* spatial, int spatial_dims, const float* center,
+                                const float* center_z, const float* dim, const float* rot_cos, const float* rot_sin,
+                                const float* vel, const float* stride_rows, int batch, int num_class, int k,
+                                float feature_map_stride, const float* voxel_size_xy, const float* range_min_xy,
+                                const float* post_center_limit_range, const float* score_thresh, float* boxes, float* scores,
+                                int* labels, int* counts, void* stream) {
+    if (batch < 0 || num_class <= 0 || k <= 0 || spatial_dims < 2 || !voxel_size_xy || !range_min_xy || !post_center_limit_range)
+        return PVX_ERR_INVALID;
+    if (k > kMaxK || batch > 65535) return PVX_ERR_RANGE;
+    if (batch == 0) return PVX_OK;
+    if (!obj || !row_begin || !spatial || !center || !center_z || !dim || !rot_cos || !rot_sin || !boxes || !scores || !labels || !counts)
+        return PVX_ERR_INVALID;
+    DecodeArgs a;
+    a.heatmap = obj; a.center = center; a.center_z = center_z; a.dim = dim; a.rot_cos = rot_cos; a.rot_sin = rot_sin; a.vel = vel;
+    a.rot_batch_stride = 0;
+    a.num_class = num_class; a.h = 0; a.w = 0; a.k = k;
+    a.stride = feature_map_stride; a.voxel_x = voxel_size_xy[0]; a.voxel_y = voxel_size_xy[1];
+    a.range_x = range_min_xy[0]; a.range_y = range_min_xy[1];
+    for (int j = 0; j < 6; j++) a.lim[j] = post_center_limit_range[j];
+    a.has_thresh = score_thresh ? 1 : 0;
+    a.score_thresh = score_thresh ? *score_thresh : 0.f;
+    a.boxes = boxes; a.scores = scores; a.labels = labels; a.counts = counts;
+    a.row_begin = row_begin; a.spatial = spatial; a.sd = spatial_dims; a.stride_rows = stride_rows;
+    hipLaunchKernelGGL(center_decode_kernel<true>, dim3(batch), dim3(kThreads), 0, (hipStream_t)stream, a);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

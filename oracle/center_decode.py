@@ -43,3 +43,37 @@ def decode_bbox_from_heatmap(heatmap, rot_cos, rot_sin, center, center_z, dim, p
             mask &= scores > F(score_thresh)                                   # :226-227
         out.append(dict(pred_boxes=boxes[mask], pred_scores=scores[mask], pred_labels=cls[mask].astype(np.int64)))
     return out
+
+
+def decode_bbox_from_voxels_nuscenes(batch_size, indices, obj, rot_cos, rot_sin, center, center_z, dim, vel=None,
+                                     point_cloud_range=None, voxel_size=None, feature_map_stride=None, K=100, score_thresh=None,
+                                     post_center_limit_range=None):
+    """centernet_utils.py:303-367 with `_topk_1d(nuscenes=True)` (:256-289) and `gather_feat_idx` (:291-301): per frame the K
+    best of obj[rows of the frame].T (class-major flat index c * rows + r), ties: lower flat index first."""
+    indices = np.asarray(indices)
+    obj = np.asarray(obj, F)
+    lim = np.asarray(post_center_limit_range, F)
+    per_row_stride = not np.isscalar(feature_map_stride)
+    out = []
+    for b in range(batch_size):
+        rows = np.nonzero(indices[:, 0] == b)[0]                               # :263 batch_inds
+        nb = len(rows)
+        flat = obj[rows].T.reshape(-1)                                         # :269 score = obj[batch_inds].permute(1, 0)
+        order = np.argsort(-flat, kind="stable")[:min(K, flat.size)]           # :270-271
+        scores = flat[order]
+        cls = order // max(nb, 1)                                              # class plane of the flat index (:274 for rows >= K)
+        row = rows[order % max(nb, 1)] if nb else rows[:0]                     # :275
+        g = lambda t, ch: np.asarray(t, F)[row, ch]                            # :291-301
+        st = np.asarray(feature_map_stride, F).reshape(-1)[row] if per_row_stride else F(feature_map_stride)
+        xs = ((indices[row, -1].astype(F) + g(center, 0)) * st) * F(voxel_size[0]) + F(point_cloud_range[0])   # :324
+        ys = ((indices[row, -2].astype(F) + g(center, 1)) * st) * F(voxel_size[1]) + F(point_cloud_range[1])   # :325
+        angle = np.arctan2(g(rot_sin, 0), g(rot_cos, 0)).astype(F)             # :323
+        parts = [xs, ys, g(center_z, 0), g(dim, 0), g(dim, 1), g(dim, 2), angle]
+        if vel is not None:
+            parts += [g(vel, 0), g(vel, 1)]
+        boxes = np.stack(parts, 1).astype(F) if len(row) else np.zeros((0, 9 if vel is not None else 7), F)
+        mask = (boxes[:, :3] >= lim[:3]).all(1) & (boxes[:, :3] <= lim[3:]).all(1)      # :345-346
+        if score_thresh is not None:
+            mask &= scores > F(score_thresh)                                   # :348-349
+        out.append(dict(pred_boxes=boxes[mask], pred_scores=scores[mask], pred_labels=cls[mask].astype(np.int64)))
+    return out

@@ -122,3 +122,24 @@ def test_center_head_post_processing_all_heads_one_nms(cuda_device):
         assert np.array_equal(gb[:, :6], wb[:, :6]) and np.array_equal(gb[:, 7:], wb[:, 7:])
         assert np.allclose(gb[:, 6], wb[:, 6], rtol=0, atol=1e-6)
     assert total > 50            # the case is not vacuous
+
+
+@pytest.mark.parametrize("rows,C,K,thr,vel,prs", [((900, 700), 2, 100, 0.1, True, False), ((400,), 1, 50, None, False, False),
+                                                  ((600, 650, 800), 3, 200, 0.2, True, True), ((30000, 25000), 2, 500, 0.1, True, False),
+                                                  ((40, 0, 500), 2, 100, None, True, False)])
+def test_sparse_decode_matches_oracle(rows, C, K, thr, vel, prs, cuda_device):
+    """VoxelNeXt form (pvx_voxel_decode through decode_bbox_from_voxels_nuscenes), incl. a frame with fewer rows than K and an
+    empty frame (the reference's torch.stack cannot express those; the natural result is checked)"""
+    from test_oracle_center_decode import make_sparse_inputs
+    d = make_sparse_inputs(len(rows) * 10 + C, rows, C, vel=vel, per_row_stride=prs)
+    t = {k: (torch.from_numpy(v).to(cuda_device) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+    got = centernet_utils.decode_bbox_from_voxels_nuscenes(len(rows), t["indices"], t["obj"], t["rot_cos"], t["rot_sin"], t["center"],
+                                                           t["center_z"], t["dim"], vel=t["vel"], point_cloud_range=GEOM["pcr"],
+                                                           voxel_size=GEOM["vs"], feature_map_stride=t["stride"], K=K,
+                                                           score_thresh=thr, post_center_limit_range=GEOM["lim"])
+    want = center_decode.decode_bbox_from_voxels_nuscenes(len(rows), d["indices"], d["obj"], d["rot_cos"], d["rot_sin"], d["center"],
+                                                          d["center_z"], d["dim"], vel=d["vel"], point_cloud_range=GEOM["pcr"],
+                                                          voxel_size=GEOM["vs"], feature_map_stride=d["stride"], K=K,
+                                                          score_thresh=thr, post_center_limit_range=GEOM["lim"])
+    check(got, want)
+    assert all(g["pred_ious"] is None and g["add_features"] is None for g in got)
