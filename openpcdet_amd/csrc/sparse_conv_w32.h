@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
 
 // shapes the 32x32 form takes (K <= 32).  CIN = 16 stays on the 16x16x32 kernel, which packs TWO kernel offsets into one
 // K = 32 MFMA step and measured faster there (profiles/r01_*)
-#define PVX_W32_SHAPES(X) X(32, 32) X(32, 64) X(64, 32) X(64, 64) X(64, 128) X(128, 64) X(128, 128)
+#define PVX_W32_SHAPES(X) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) X(64, 64) X(64, 128) X(128, 64) X(128, 128)
 
 inline bool w32_shape(int cin, int cout, int K, int dtype) {
     if (dtype == PVX_F32 || K > kMaxKLds || conv_impl() != 3) return false;
