@@ -366,7 +366,7 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
             constexpr bool PF = S <= 4 && WGS == 1;   // at two workgroups per CU (128 VGPRs) the second row buffer spills
             int rr9[GK];
 #pragma unroll
-            for (int kk = 0; kk < GK; kk++) rr9[kk] = my_n[kk * TM];
+            for (int kk = 0; kk < GK; kk++) rr9[kk] = WGS == 1 ? my_n[kk * TM] : 0;   // at 128 VGPRs they are read per offset instead
             auto load_b = [&](int r, u32x4 (&bb)[S]) {
                 const int local = r - lo;
                 const bool in_lds = r >= 0 && local >= 0 && local < cnt;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
                         for (int q = 0; q < NW; q++) wreg[q] = wlane ? w2[q * NT + tid] : zero4;
                     }
                 }
-                const int rr = rr9[kk];
+                const int rr = WGS == 1 ? rr9[kk] : my_n[kk * TM];
                 const bool on = __ballot(rr >= 0) != 0ull;     // wave-uniform; the barrier below is outside
                 if (PF) { if (kk + 1 < GK) load_b(rr9[kk + 1], bq[(kk + 1) & 1]); }
                 else if (on) load_b(rr, bq[0]);
