@@ -310,7 +310,7 @@ def main():
             traffic, traffic_src = round(tot_b / n_l), "profiles/" + os.path.basename(tpath)
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "sparse_conv_w32_kernel + sparse_conv_slab_kernel + sparse_conv_mfma2_kernel (%d conv launches/step)" % conv_launches,
+                    "kernel": "sparse_conv_slab_stream_kernel + sparse_conv_slab_kernel + sparse_conv_w32_kernel (%d conv launches/step)" % conv_launches,
                     "flops_per_step": flops, "ms_per_step": round(conv_ms, 4)}
         # the HBM-bound stages against the 8 TB/s roof, ALGORITHMIC bytes over the stage's own launch time
         n_pts = sum(int(f.shape[0]) for f in frames[:B])
