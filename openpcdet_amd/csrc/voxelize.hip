@@ -16,7 +16,8 @@
 //               (block sums scanned by one workgroup) ranks the first points in input order: that rank IS
 //               the sequential voxel id.  Cells with rank >= max_voxels are exactly the ones the sequential
 //               algorithm refuses;
-//   3. bucket   every point of a kept cell pushes its index through an atomicMin cascade over the cell's T
+//   3. bucket   (slot 0 of a cell's list is its first point, stored by the rank kernel) every other point of a kept cell
+//               pushes its index through an atomicMin cascade over the cell's remaining T - 1
 //               slots; whatever the arrival order, slot t ends up holding the (t+1)-th smallest point index;
 //   4. gather   one thread per (voxel, channel) copies the <= T points in order, zero-fills the rest,
 //               counts them and (fused MeanVFE) divides the running sum by max(count, 1).
@@ -164,9 +165,10 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
                                                                int max_voxels, int* __restrict__ vid_of_slot,
                                                                int* __restrict__ coords_zyx, int* __restrict__ coords_bzyx,
                                                                int batch_idx, const int* __restrict__ row_base_dev,
-                                                               int row_capacity) {
+                                                               int row_capacity, int* __restrict__ lists, int T) {
     __shared__ int wave_sums[kScanBlk / 64];
     const size_t f = blockIdx.y;
+    lists += f * (size_t)max_voxels * T;
     slot_of_point += f * (size_t)n; table += f * table_slots; vid_of_slot += f * table_slots;
     block_offsets += f * gridDim.x;
     if (coords_zyx) coords_zyx += f * (size_t)max_voxels * 3;
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(const int* __restr
     if (flag) {
         vid_of_slot[s] = rank;
         if (rank < max_voxels) {
+            lists[(size_t)rank * T] = i;     // the voxel's first point is its smallest index: slot 0 is final, no atomic ever touches it
             unsigned long long key = word >> 32;
             const int cx = (int)(key % (unsigned long long)g.gx); key /= (unsigned long long)g.gx;
             const int cy = (int)(key % (unsigned long long)g.gy);
@@ -211,8 +214,11 @@ __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict_
     // Slot values only ever decrease, so a slot seen holding a smaller index (plain, possibly stale read) holds one for
     // good and this index belongs behind it: skip those slots instead of paying one atomic round trip each (points mostly
     // arrive in index order, so a voxel's m-th point would otherwise walk m occupied slots).
-    int t0 = 0;
-    for (int t = 0; t < T; t++) {
+    // Slot 0 was written by vox_assign (the cell's first point), so first points are done and everybody else starts at slot 1:
+    // single-point voxels cost no atomic at all.
+    if (L[0] == i) return;
+    int t0 = 1;
+    for (int t = 1; t < T; t++) {
         if (L[t] < i) t0 = t + 1; else break;
     }
     int v = i;
@@ -385,7 +391,7 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
                        w.block_sums, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
-                       o.row_capacity);
+                       o.row_capacity, w.lists, T);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,
                        max_voxels, w.lists, o.point_to_voxel);
