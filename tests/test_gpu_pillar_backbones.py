@@ -1,0 +1,114 @@
+"""PillarBackBone8x / PillarRes18BackBone8x against the oracle: the sparse stages are walked layer by
+layer with the oracle's 2-D rulebooks (a [1, H, W] grid) and sparse conv, BatchNorm folded from the running statistics; the dense
+stage against torch on the CPU."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from openpcdet_amd import backbones_2d
+from openpcdet_amd.spconv import pytorch as spconv
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def randomize_bn(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.weight.data = torch.rand(m.num_features, generator=g) * 0.5 + 0.75
+            m.bias.data = torch.randn(m.num_features, generator=g) * 0.1
+            m.running_mean.data = torch.randn(m.num_features, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.num_features, generator=g) * 0.5 + 0.5
+
+
+def bn_np(f, m):
+    s = (m.weight / torch.sqrt(m.running_var + m.eps)).detach().numpy()
+    return f * s + (m.bias.detach().numpy() - m.running_mean.detach().numpy() * s)
+
+
+class Walker:
+    """features / coordinates (b, 0, y, x) of the current level, rulebooks cached per indice_key"""
+
+    def __init__(self, feat, coords3, shape):
+        self.f = feat
+        self.c = np.concatenate([coords3[:, :1], np.zeros((len(coords3), 1), np.int32), coords3[:, 1:]], 1).astype(np.int32)
+        self.shape = [1] + list(shape)
+        self.books = {}
+
+    def conv(self, cv, f=None):
+        f = self.f if f is None else f
+        w = cv.weight.detach().numpy().reshape(cv.out_channels, 9, cv.in_channels)
+        b = cv.bias.detach().numpy() if cv.bias is not None else None
+        if cv.subm:
+            key = (cv.indice_key, tuple(self.shape))
+            if key not in self.books:
+                self.books[key] = loader.subm_rulebook(self.c, self.shape, (1, 3, 3))
+            return loader.sparse_conv_fwd(f, w, b, self.books[key])
+        oc, nbr, out_shape = loader.sparse_rulebook(self.c, self.shape, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        out = loader.sparse_conv_fwd(f, w, b, nbr)
+        self.c, self.shape = oc, list(out_shape)
+        return out
+
+    def run(self, stage):
+        for unit in stage:
+            if isinstance(unit, backbones_2d.SparseBasicBlock2d):
+                h = np.maximum(bn_np(self.conv(unit.conv1), unit.bn1), 0)
+                self.f = np.maximum(bn_np(self.conv(unit.conv2, h), unit.bn2) + self.f, 0)
+            else:
+                cv, bn = unit[0], unit[1]
+                self.f = np.maximum(bn_np(self.conv(cv), bn), 0)
+        return self.c[:, [0, 2, 3]].copy(), self.f.copy()
+
+
+@pytest.mark.parametrize("cls", [backbones_2d.PillarBackBone8x, backbones_2d.PillarRes18BackBone8x])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 2e-2)])
+def test_pillar_backbone_vs_oracle(cls, dtype, tol, cuda_device):
+    torch.manual_seed(5)
+    H, W, B = 96, 112, 2
+    net = cls(model_cfg=None, input_channels=32, grid_size=np.array([W, H, 1]))
+    randomize_bn(net, 6)
+    net.eval()
+    cpu_net = copy.deepcopy(net)
+    r = np.random.default_rng(8)
+    coords = []
+    for b in range(B):
+        # pillars along a few "walls" + scattered ones, so that neighbours exist
+        yy = np.concatenate([r.integers(0, H, 600), np.clip((np.sin(np.arange(500) / 40.0) * 30 + 48).astype(int), 0, H - 1)])
+        xx = np.concatenate([r.integers(0, W, 600), np.arange(500) % W])
+        coords.append(np.stack([np.full_like(yy, b), yy, xx], 1))
+    coords = np.unique(np.concatenate(coords, 0), axis=0).astype(np.int32)
+    r.shuffle(coords, axis=0)
+    feat = r.normal(size=(len(coords), 32)).astype(np.float32)
+    feat_in = torch.from_numpy(feat).to(dtype).float().numpy()                   # what the device path sees
+    net = net.to(cuda_device).to(dtype)
+    with torch.no_grad():
+        bd = net({"pillar_features": torch.from_numpy(feat).to(cuda_device).to(dtype),
+                  "pillar_coords": torch.from_numpy(coords).to(cuda_device).float(), "batch_size": B})
+    ms = bd["multi_scale_2d_features"]
+    assert bd["multi_scale_2d_strides"] == {"x_conv1": 1, "x_conv2": 2, "x_conv3": 4, "x_conv4": 8, "x_conv5": 16}
+    w = Walker(feat_in, coords, [H, W])
+    for name in ("x_conv1", "x_conv2", "x_conv3"):
+        wc, wf = w.run(getattr(cpu_net, name.replace("x_", "")))
+        assert np.array_equal(ms[name].indices.cpu().numpy(), wc), name
+        assert rel_l2(ms[name].features.float().cpu().numpy(), wf) <= tol, name
+    wc, wf = w.run(cpu_net.conv4)
+    want4 = loader.dense(wf, w.c, B, w.shape)[:, :, 0]
+    assert ms["x_conv4"].shape == (B, 256, H // 8, W // 8)
+    assert rel_l2(ms["x_conv4"].float().cpu().numpy(), want4) <= tol
+    with torch.no_grad():
+        want5 = cpu_net.conv5(torch.from_numpy(want4.astype(np.float32))).numpy()
+    assert ms["x_conv5"].shape == want5.shape == (B, 256, H // 16, W // 16)
+    assert rel_l2(ms["x_conv5"].float().cpu().numpy(), want5) <= 2 * tol
+    # the state dict carries the reference's key names (spconv_backbone_2d.py:124-156, 217-249)
+    keys = set(net.state_dict().keys())
+    probe = ("conv1.0.conv1.bias", "conv2.0.0.weight", "conv5.1.conv1.weight") if cls.residual else \
+            ("conv1.0.0.weight", "conv2.0.0.weight", "conv5.1.0.weight")
+    assert all(k in keys for k in probe)
