@@ -352,6 +352,16 @@ int pvx_voxel_decode(const float* obj, const int* row_begin, const int* spatial,
                      const float* voxel_size_xy, const float* range_min_xy, const float* post_center_limit_range,
                      const float* score_thresh, float* boxes, float* scores, int* labels, int* counts, void* stream);
 
+/* ---- voxel query ---------------------------------------------------------------------------
+ * For each of the m queries (new_xyz [m,3], new_coords [m,4] = b, z, y, x cell): the rows of up to nsample occupied voxels in
+ * the cell neighbourhood +-max_range_zyx whose centre xyz[row] is within `radius` of the query, in ascending (dz, dy, dx)
+ * order; a row is pre-filled with its first hit; queries without a hit get zeros and empty_mask[q] = 1 (optional).
+ * point_indices [batch, z, y, x] int32 is the dense voxel -> row map (-1 = empty; common_utils.py:253-270).
+ * Replaces voxel_query_gpu.cu:10-89 + voxel_query_utils.py:34-41 (VoxelQuery.forward). */
+int pvx_voxel_query(const float* new_xyz, const int* new_coords, int m, const float* xyz, int n_voxels, const int* point_indices,
+                    int batch, int z, int y, int x, const int* max_range_zyx, float radius, int nsample, int* idx,
+                    unsigned char* empty_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

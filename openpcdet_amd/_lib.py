@@ -63,6 +63,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pvx_voxel_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, ctypes.c_float] +
                          [c_void_p] * 9),
+    "pvx_voxel_query": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                        ctypes.c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_sort_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
     "pvx_site_index_bytes": (c_size_t, [c_int, c_void_p]),
