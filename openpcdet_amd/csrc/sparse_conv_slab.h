@@ -14,8 +14,8 @@
 // such as first-come voxel rows, or a tile that straddles two z-planes) falls back to range-checked buffer gathers.
 #pragma once
 
-template <typename E, int CIN, int COUT, int RCAP>
-__global__ __launch_bounds__(512) void sparse_conv_slab_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
+template <typename E, int CIN, int COUT, int RCAP, int WGS>
+__global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
                                                                const uint4* __restrict__ wfrag, const int* __restrict__ nbr,
                                                                int n_out, const int* __restrict__ n_out_dev,
                                                                const float* __restrict__ bias, const float* __restrict__ scale,
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(16, 16, 1024, 2) X(16, 32, 1024, 2) X(32, 32, 768, 2) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
+#define PVX_SLAB_SHAPES(X) X(16, 16, 896, 3) X(16, 32, 896, 3) X(32, 32, 768, 2) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
@@ -496,15 +496,15 @@ int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n
                 const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
     const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
-    int grid = num_cus() * (STREAM == 2 ? 2 : 1);      // workgroups per CU that LDS (and the launch bounds) admit
+    int grid = num_cus() * (STREAM >= 2 ? 2 : 1);      // workgroups per CU that LDS (and the launch bounds) admit
     const int tiles = PVX_CDIV(n_out, 256);
     if (grid > tiles) grid = (tiles + 7) / 8 * 8;
-    if constexpr (STREAM != 0) {
+    if constexpr (STREAM == 1 || STREAM == 2) {
         hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP, (STREAM == 2 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
                            (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
                            relu, (E*)out);
     } else {
-        hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+        hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP, (STREAM == 3 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
                            (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
                            relu, (E*)out);
     }
