@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
 // Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
 // MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
 // on the register-gather kernel.
-#define PVX_SLAB_SHAPES(X) X(16, 16, 896, 3) X(16, 32, 896, 3) X(32, 32, 440, 3) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
+#define PVX_SLAB_SHAPES(X) X(16, 16, 896, 3) X(16, 32, 896, 3) X(32, 32, 440, 3) X(32, 64, 1024, 0) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
     static int v = -1;
