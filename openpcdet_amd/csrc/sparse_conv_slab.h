@@ -471,10 +471,11 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
     }
 }
 
-// shapes with a slab form: K = 27 (3 x 3 x 3), LDS = 9 offsets of weights + the rulebook slice + RCAP rows.
-// Measured (profiles/r01_d_conv_variants.txt): 64 -> 64 @ 0.66 M sites 347 -> 251 us; the CIN = 32 shapes do not gain (two
-// MFMAs per offset are too little work to amortise the three load phases per tile: 236 -> 237 us, 140 -> 156 us), so they stay
-// on the register-gather kernel.
+// Shapes with a slab form (K = 27): X(cin, cout, window rows, mode).  mode 0 = sparse_conv_slab_kernel (the group's nine offsets of
+// weights resident in LDS) at one workgroup per CU, 3 = the same at two per CU (<= 80 KiB LDS, 128 VGPRs); 1 / 2 =
+// sparse_conv_slab_stream_kernel (one offset of weights at a time) at one / two workgroups per CU.  The assignment below was
+// chosen by A/B runs of the whole overlapped bench on one GPU box, not by isolated kernel times, which rank some of the forms
+// differently (profiles/r01_d_conv_variants.txt, last section).
 #define PVX_SLAB_SHAPES(X) X(16, 16, 896, 3) X(16, 32, 896, 3) X(32, 32, 440, 3) X(32, 64, 1024, 0) X(64, 64, 384, 0) X(64, 128, 832, 1) X(128, 64, 440, 1) X(128, 128, 320, 1)
 
 inline bool slab_enabled() {
