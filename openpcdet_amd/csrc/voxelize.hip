@@ -9,7 +9,7 @@
 // of a voxel in input order, cells first seen after max_voxels ids were given are dropped).  The parallel
 // formulation that reproduces it bit-for-bit, independent of thread timing:
 //   1. insert   every in-range point CASes the 64-bit word (cell key << 32 | point index) into an open-addressing table
-//               in HBM (linear probing, load factor <= 0.5); a point that finds its cell already there lowers the word
+//               in HBM (linear probing, load factor <= 2/3); a point that finds its cell already there lowers the word
 //               with atomicMin only if it carries a smaller index, so every occupied slot ends up knowing the FIRST
 //               point of its cell at ~1.1 atomics per point;
 //   2. rank     point i is a "first point" iff first[slot(i)] == i.  A wavefront ballot + popcount prefix
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlk) void mean_vfe_kernel(const float* __restrict_
 
 size_t table_capacity(int n) {
     size_t cap = 1024;
-    while (cap < (size_t)n * 2 + 2) cap <<= 1;
+    while (cap < (size_t)n + (size_t)n / 2 + 2) cap <<= 1;   // load factor <= 2/3 even if every point opens its own cell
     return cap;
 }
 
