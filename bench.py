@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--no-vox-ahead", action="store_true",
                     help="voxelize each batch inside its own step instead of one step ahead, beside the previous batch's rulebooks")
+    ap.add_argument("--geo-after", type=int, default=3,
+                    help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 3 measured best "
+                         "for this backbone: profiles/r01_d_conv_variants.txt)")
     ap.add_argument("--geometry-cus", type=int, default=0,
                     help="CUs reserved for the geometry / NMS streams (CU-masked streams; 0 = shared CUs, priority streams)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
@@ -198,6 +201,16 @@ def main():
         if pipelined:
             plan = eng if i % 2 == 0 else eng2
             cur = torch.cuda.current_stream(dev)
+            if vox_ahead and args.geo_after > 0:
+                # as below, but the next batch's geometry is held back until a chosen conv layer of this batch has been reached
+                nxt = eng2 if i % 2 == 0 else eng
+                with torch.cuda.stream(nms_stream):
+                    load_boxes(i)
+                    result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
+                plan.forward(overlap=True, pipelined=True, prevoxelized=True, mark_after=args.geo_after)
+                nxt.voxelize_ahead(vox_stream, load=lambda: load_points(i + 1, nxt), after=plan.mark)
+                cur.wait_stream(nms_stream)
+                return
             if vox_ahead:
                 # batch i was voxelized during step i-1; batch i+1 is voxelized now, on its own stream, beside batch i's rulebooks
                 nxt = eng2 if i % 2 == 0 else eng
@@ -339,7 +352,7 @@ def main():
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
                        "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
-                       "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "rows_per_level": rows},
+                       "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "geo_after": args.geo_after, "rows_per_level": rows},
             "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
                        "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},

@@ -310,7 +310,7 @@ class HotPathEngine:
 
     _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
 
-    def voxelize_ahead(self, stream, load=None):
+    def voxelize_ahead(self, stream, load=None, after=None):
         """Voxelize the NEXT batch of this plan on `stream` while another plan's rulebooks are being built: waits for this
         plan's previous forward (whose convs read the level-0 rows and counts), calls `load()` (which copies the frames into
         `self.points` on `stream`), voxelizes, and records the event that `forward(prevoxelized=True)` waits for.  The
@@ -321,12 +321,14 @@ class HotPathEngine:
                 self._vox_done = torch.cuda.Event()
             with torch.cuda.stream(stream):
                 stream.wait_event(self._done)
+                if after is not None:
+                    stream.wait_event(after)      # e.g. another plan's `mark` event: start beside a chosen conv layer
                 if load is not None:
                     load()
                 self.voxelize(stream.cuda_stream)
                 self._vox_done.record(stream)
 
-    def forward(self, overlap=True, pipelined=False, prevoxelized=False):
+    def forward(self, overlap=True, pipelined=False, prevoxelized=False, mark_after=None):
         """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
         static buffer) or None.  No host synchronisation.
 
@@ -360,6 +362,9 @@ class HotPathEngine:
                 pending = self._geo_events[0]
                 pending.record(geo)
                 i = 1
+                n_conv = 0
+                if mark_after is not None and getattr(self, "mark", None) is None:
+                    self.mark = torch.cuda.Event()
                 for name, fn in self.ops:
                     if name in self._GEOMETRY:
                         fn(g)
@@ -371,6 +376,10 @@ class HotPathEngine:
                             main.wait_event(pending)
                             pending = None
                         fn(m)
+                        if mark_after is not None and name.startswith("conv"):
+                            n_conv += 1
+                            if n_conv == mark_after:
+                                self.mark.record(main)    # the mark_after-th conv launch of this forward has been enqueued
                 if pending is not None:
                     main.wait_event(pending)
                 self._done.record(main)

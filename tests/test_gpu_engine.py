@@ -289,9 +289,16 @@ def test_voxelize_ahead_cu_budget_and_masked_streams(cuda_device):
         dev_frames = to_dev(fr)
         torch.cuda.synchronize()
         eng.voxelize_ahead(side, load=lambda: eng.load_points(dev_frames))
-        got = eng.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
+        got = eng.forward(overlap=True, pipelined=True, prevoxelized=True, mark_after=3).clone()
         torch.cuda.synchronize()
         assert torch.equal(got, w)
+        assert eng.mark.query()                      # the mark event after the third conv launch was recorded and has completed
+    # a later voxelize_ahead may be held back behind such a mark
+    dev_frames = to_dev(frames_a)
+    eng.voxelize_ahead(side, load=lambda: eng.load_points(dev_frames), after=eng.mark)
+    got = eng.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want[0])
     # 2. conv CU budget: fewer, longer-running workgroups, same sums
     try:
         assert L.pvx_sparse_conv_set_cu_budget(64) == 0
