@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the conv stream (A/B switch)")
     ap.add_argument("--no-pipeline", action="store_true", help="one plan: geometry overlaps only the convs of its own batch")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no geometry / conv / NMS overlap (A/B switch)")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle baseline (0 = skip); 6 frames = ~15 s of CPU work")
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
