@@ -7,8 +7,10 @@ hipcc cross-compiles without a GPU, so this runs in the build container; the res
 GPU box with the tree (it is git-ignored, not gpurun-ignored).
 """
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -62,10 +64,14 @@ def build(force=False, verbose=True):
         if verbose:
             print("up to date:", LIB)
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # link in a scratch directory and move the result: hipcc leaves empty `<out>.N.host-*` temporaries beside its output
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, os.path.basename(LIB))
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        shutil.move(out, LIB)
     if verbose:
         print("built:", LIB)
     return LIB
