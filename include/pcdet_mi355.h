@@ -81,6 +81,16 @@ int pvx_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, 
 int pvx_nms_batched(const float* boxes, const int* counts, int segments, int n_cap, float thresh, int normal,
                     int64_t* keep, int* num_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* pvx_nms for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc) and bring no workspace: the suppression mask lives in a static device array inside the library
+ * (PVX_NMS_STATIC_MAX^2 / 8 bytes = 2 MiB per GPU the library runs on, held until the process ends).  Calls no
+ * hipMalloc / hipFree or any allocating routine; n > PVX_NMS_STATIC_MAX returns PVX_ERR_RANGE.  Same results as
+ * pvx_nms (same kernels).  It has NO counterpart in the reference.  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams) race; calls on one stream are ordered and need no clearing.
+ * The array's address is resolved on the first call per device (hipGetSymbolAddress; make that call outside capture). */
+#define PVX_NMS_STATIC_MAX 4096
+int pvx_nms_static(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep, void* stream);
+
 /* HOST functions on HOST pointers -- the reference keeps CPU entry points in the same module because
  * DataLoader workers call them (pcdet/datasets/augmentor/database_sampler.py:489-493); they create no GPU
  * context.  Replace boxes_iou_bev_cpu / boxes_aligned_iou_bev_cpu (iou3d_cpu.cpp:232-273). */

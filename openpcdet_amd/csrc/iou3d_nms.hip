@@ -11,6 +11,7 @@
 //    iou3d_nms.cpp:155-179);
 //  * many independent problems (heads x frames) go in one launch through a segment table.
 // Build flags for this TU: -ffp-contract=off (see iou_core.h).
+#include <atomic>
 #include "pvx_common.h"
 #include "iou_core.h"
 
@@ -265,6 +266,21 @@ extern "C" size_t pvx_nms_workspace_bytes(int n_cap, int segments) {
     return s.total();
 }
 
+// mask kernel + scan kernel over a caller-resolved mask buffer: shared by the workspace entry points and pvx_nms_static
+static int nms_run(const float* boxes, const int* counts, int segments, int n_cap, int cb_cap, float thresh, int normal,
+                   int64_t* keep, int* num_keep, unsigned long long* mask, hipStream_t st) {
+    dim3 grid(cb_cap, cb_cap, segments);
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(segments), dim3(kBlock), 0, st, mask, counts, n_cap, n_cap, cb_cap,
+                       (long long*)keep, num_keep);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
 extern "C" int pvx_nms_batched(const float* boxes, const int* counts, int segments, int n_cap, float thresh, int normal,
                                int64_t* keep, int* num_keep, void* workspace, size_t workspace_bytes, void* stream) {
     if (segments < 0 || n_cap < 0 || !num_keep) return PVX_ERR_INVALID;
@@ -281,22 +297,53 @@ extern "C" int pvx_nms_batched(const float* boxes, const int* counts, int segmen
     PvxCarver ws(workspace, workspace_bytes);
     unsigned long long* mask = ws.take<unsigned long long>((size_t)segments * n_cap * cb_cap);
     if (!ws.ok() || !mask) return PVX_ERR_WORKSPACE;
-    dim3 grid(cb_cap, cb_cap, segments);
-    if (normal)
-        hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
-    else
-        hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
-    PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(segments), dim3(kBlock), 0, st, mask, counts, n_cap, n_cap, cb_cap,
-                       (long long*)keep, num_keep);
-    PVX_CHECK_LAUNCH();
-    return PVX_OK;
+    return nms_run(boxes, counts, segments, n_cap, cb_cap, thresh, normal, keep, num_keep, mask, st);
 }
 
 extern "C" int pvx_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep,
                        void* workspace, size_t workspace_bytes, void* stream) {
     if (n < 0) return PVX_ERR_INVALID;
     return pvx_nms_batched(boxes, nullptr, 1, n, thresh, normal, keep, num_keep, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pvx_nms_static: pvx_nms with the suppression mask in the library's own static device array, for callers that can
+// neither allocate nor bring a workspace (the reference's nms_gpu signature has none either, iou3d_nms.cpp:137).
+// `scratch` below is a host-side stand-in for the symbol; the device address is resolved once per device with
+// hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+// ---------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned long long scratch[(size_t)PVX_NMS_STATIC_MAX * (PVX_NMS_STATIC_MAX / 64)];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<unsigned long long*> g_static_mask[kMaxDevices];
+}
+
+extern "C" int pvx_nms_static(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep,
+                              void* stream) {
+    if (n < 0 || !num_keep) return PVX_ERR_INVALID;
+    if (n > PVX_NMS_STATIC_MAX) return PVX_ERR_RANGE;        // the static mask holds PVX_NMS_STATIC_MAX x PVX_NMS_STATIC_MAX bits
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {
+        PVX_CHECK_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), st));
+        return PVX_OK;
+    }
+    if (!boxes || !keep) return PVX_ERR_INVALID;
+    int dev = -1;
+    PVX_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return PVX_ERR_RANGE;
+    unsigned long long* mask = g_static_mask[dev].load(std::memory_order_acquire);
+    if (!mask) {
+        // first call on this device (it is the current one): every GPU holds its own copy of the array at its own address
+        void* p = nullptr;
+        PVX_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return PVX_ERR_HIP;
+        mask = (unsigned long long*)p;
+        g_static_mask[dev].store(mask, std::memory_order_release);
+    }
+    // Nothing has to be cleared between calls: the scan reads mask word (row, w) only for row < n and w >= row / 64, and the
+    // mask kernel of the same call writes exactly those words (tiles R <= C with C * 64 < n) before the scan starts.
+    return nms_run(boxes, nullptr, 1, n, PVX_CDIV(n, 64), thresh, normal, keep, num_keep, mask, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
