@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpcdet_mi355.so")
+LIB_PATH = os.environ.get("PVX_LIB") or os.path.join(_HERE, "lib", "libpcdet_mi355.so")   # PVX_LIB: a diagnostic build of the same library
 
 PVX_OK = 0
 _ERR = {-1: "PVX_ERR_INVALID", -2: "PVX_ERR_WORKSPACE", -3: "PVX_ERR_HIP", -4: "PVX_ERR_RANGE"}

@@ -45,7 +45,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
             and os.path.getmtime(obj) > _headers_mtime()):
         return obj
-    cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ["-c", spath, "-o", obj]
+    cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + os.environ.get("PVX_EXTRA_CFLAGS", "").split() + ["-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -642,7 +642,7 @@ int num_cus() {
         if (e && g_cu_budget == 0) g_cu_budget = atoi(e);
     }
     if (g_cu_budget >= 8 && g_cu_budget < cus) return g_cu_budget / 8 * 8;   // the same number in each of the 8 XCDs
-    return cus;
+    return (cus + 7) / 8 * 8;   // grids are multiples of 8: the XCD-aware tile walk gives every XCD the same number of workgroups
 }
 
 // timing-only ablation (cdna_hip_programming.md section 7): PVX_ABLATE_GATHER=1 gives the feature buffer descriptor
@@ -669,6 +669,7 @@ int conv_impl() {
 
 #include "sparse_conv_w32.h"
 #include "sparse_conv_slab.h"
+#include "sparse_conv_v3.h"
 
 long long prepared_elems(int cout, int K, int cin, int dtype) {
     if (w32_shape(cin, cout, K, dtype)) {
@@ -829,7 +830,19 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
     if (!prepared_weight || !nbr || !out || (n_in > 0 && !feat_in)) return PVX_ERR_INVALID;
     if ((long long)n_out * cout > 0x7fffffff00ll) return PVX_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
-    if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
+    if (w32_shape(cin, cout, kvol, dtype) && v3_shape(cin, cout, kvol, dtype)) {
+        int rcv = PVX_ERR_INVALID;
+#define X(ci, co, ck, rc, nwb, wgs)                                                                                           \
+    if (cin == ci && cout == co) {                                                                                            \
+        if (dtype == PVX_BF16)                                                                                                \
+            rcv = launch_v3<__bf16, ci, co, ck, rc, nwb, wgs>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+        else                                                                                                                  \
+            rcv = launch_v3<_Float16, ci, co, ck, rc, nwb, wgs>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+    }
+        PVX_V3_SHAPES(X)
+#undef X
+        if (rcv != PVX_OK) return rcv;
+    } else if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
         int rcs = PVX_ERR_INVALID;
 #define X(ci, co, rc, sm)                                                                                                     \
     if (cin == ci && cout == co) {                                                                                            \
