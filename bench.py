@@ -67,19 +67,45 @@ def make_inputs(cfg, rank, pool, dev):
     return frames, torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(counts).to(dev)
 
 
-def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts):
-    """the oracle chain on host cores: (frames/s, threads, description)"""
+def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts, single_thread_frames=0):
+    """the oracle chain on host cores: one untimed warm-up frame, then n_frames timed frames; frames/s from the MEDIAN frame time
+    -> (frames/s, threads, description, frames/s on one thread or None)"""
     from oracle import chain, loader
     threads = int(loader.oracle().orc_num_threads())
-    t_total = 0.0
-    for i in range(n_frames):
+
+    def one(i):
         pts = synth.config_cloud(WORKLOAD, 3 + i)
         t0 = time.perf_counter()
         chain.backbone_chain(net_cpu, [pts], cfg)
         chain.heads_nms(boxes[i], scores[i], counts[i], NMS_THRESH, NMS_POST)
-        t_total += time.perf_counter() - t0
-    return n_frames / t_total, threads, "%d full frames (300k points each), fp32, all stages; convs on %d OpenMP threads, " \
-        "voxelizer / rulebook / NMS single-threaded" % (n_frames, threads)
+        return time.perf_counter() - t0
+
+    one(0)
+    ts = sorted(one(i) for i in range(n_frames))
+    med = ts[len(ts) // 2]
+    single = None
+    if single_thread_frames > 0:
+        prev = torch.get_num_threads()
+        loader.oracle().orc_set_num_threads(1)
+        torch.set_num_threads(1)
+        t1 = sorted(one(i) for i in range(single_thread_frames))
+        single = 1.0 / t1[len(t1) // 2]
+        torch.set_num_threads(prev)
+        loader.oracle().orc_set_num_threads(threads)
+    return 1.0 / med, threads, "1 warm-up + %d timed full frames (300k points each), median frame time, fp32, all stages; convs on %d " \
+        "OpenMP threads, voxelizer / rulebook / NMS single-threaded" % (n_frames, threads), single
+
+
+# which HIP kernel a (cin, cout, kernel volume) layer of this backbone launches (csrc/sparse_conv_slab.h PVX_SLAB_SHAPES,
+# csrc/sparse_conv_w32.h); the names are the ones rocprofv3 --kernel-trace --stats prints
+def conv_kernel_name(cin, cout, kvol):
+    if os.environ.get("PVX_CONV_V3", "0") != "0" and kvol == 27 and (cin, cout) in ((64, 64), (128, 128), (64, 128)):
+        return "sparse_conv_v3_kernel<bf16,%d,%d>" % (cin, cout)
+    if kvol == 27 and (cin, cout) in ((16, 16), (16, 32), (32, 32), (32, 64), (64, 64)):
+        return "sparse_conv_slab_kernel<bf16,%d,%d>" % (cin, cout)
+    if kvol == 27 and (cin, cout) in ((64, 128), (128, 64), (128, 128)):
+        return "sparse_conv_slab_stream_kernel<bf16,%d,%d>" % (cin, cout)
+    return "sparse_conv_w32_kernel<bf16,%d,%d>" % (cin, cout)
 
 
 def main():
@@ -97,12 +123,14 @@ def main():
                     help="CUs reserved for the geometry / NMS streams (CU-masked streams; 0 = shared CUs, priority streams)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
-    ap.add_argument("--graph", action="store_true", help="capture the step in a HIP graph and replay it (the default launches "
-                    "eagerly: the step is device-bound, ~110 launches against several ms of kernels)")
+    ap.add_argument("--graph", action="store_true", help="capture one plan's step -- convs, geometry stream and NMS stream forked from and joined "
+                    "to the capturing stream -- in a HIP graph and replay it.  The default launches eagerly (the step is device-bound) and "
+                    "alternates two plans, whose cross-step event waits a single capture cannot hold")
     ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the conv stream (A/B switch)")
     ap.add_argument("--no-pipeline", action="store_true", help="one plan: geometry overlaps only the convs of its own batch")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no geometry / conv / NMS overlap (A/B switch)")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-oracle baseline (0 = skip); 6 frames = ~15 s of CPU work")
+    ap.add_argument("--cpu-frames", type=int, default=5, help="timed frames of the CPU-oracle baseline after one warm-up frame (0 = skip); ~15 s of CPU work")
+    ap.add_argument("--cpu-single-frames", type=int, default=0, help="also time this many frames with the oracle on ONE thread (~35 s each; profiles/ only)")
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
@@ -158,7 +186,7 @@ def main():
 
     def hot_path():
         # the NMS of the decoded boxes shares nothing with the backbone: it runs on its own stream beside it
-        if args.no_overlap or args.graph:
+        if args.no_overlap:
             eng.forward(overlap=False)
             result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
             return
@@ -274,6 +302,19 @@ def main():
 
     out = None
     if rank == 0:
+        # ---- the last timed step's results against a serial, single-stream re-run of the same batch on the same kernels: the
+        #      overlapped schedule (4 streams, 2 plans, or the graph replay) must not change a bit ----
+        i_last = args.warmup + args.steps - 1
+        plan_last = (eng if i_last % 2 == 0 else eng2) if pipelined else eng
+        bev_last, sel_last, num_last = plan_last.dense.clone(), result["sel"].clone(), result["num"].clone()
+        load(i_last)
+        eng.forward(overlap=False)
+        sel_s, num_s = nms(s_boxes, s_scores, s_counts)
+        torch.cuda.synchronize()
+        checked = {"bev_bitwise_equal_to_serial_rerun": bool(torch.equal(bev_last, eng.dense)),
+                   "nms_equal_to_serial_rerun": bool(torch.equal(num_last, num_s) and torch.equal(sel_last, sel_s)),
+                   "bev_nonzero": int((bev_last != 0).sum().item())}
+        assert checked["bev_bitwise_equal_to_serial_rerun"] and checked["nms_equal_to_serial_rerun"] and checked["bev_nonzero"] > 0, checked
         # ---- instrumented pass: HIP events around every launch of the plan, on the stream they are launched on ----
         ev = {}
 
@@ -311,20 +352,59 @@ def main():
         nms_ms = sum(a.elapsed_time(b) for a, b in stage_ev["nms"]) / passes
         flops, per_layer = eng.conv_flops()     # of the last loaded batch
         achieved = flops / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per conv launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, FETCH_SIZE doubled as the gfx950 note prescribes: tools/pmc_traffic.py); null when the file is absent
-        traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_b%d.json" % B)
-        if os.path.exists(tpath):
-            rows_t = [r for r in json.load(open(tpath)) if r["kernel"].startswith("sparse_conv")]
-            passes_t = max(1, min(r["launches"] for r in rows_t))
-            tot_b = sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] / passes_t for r in rows_t)
-            n_l = sum(r["launches"] / passes_t for r in rows_t)
-            traffic, traffic_src = round(tot_b / n_l), "profiles/" + os.path.basename(tpath)
+        # per kernel: launches of one step grouped by the HIP kernel they run; algorithmic flops 2 P Cin Cout and compulsory bytes
+        # (N_in Cin e + N_out Cout e + K N_out 4 [+ residual rows]) per launch over the launch's event-timed duration
+        groups = {}
+        for (lname, n_rows, pairs, f), rec in zip(per_layer, eng.conv_records):
+            kname = conv_kernel_name(rec["cin"], rec["cout"], rec["kvol"])
+            n_in = min(int(rec["level_in"].n_dev.item()), rec["level_in"].cap)
+            byts = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 * (2 if rec["residual"] else 1) + rec["kvol"] * n_rows * 4 + \
+                rec["kvol"] * rec["cin"] * rec["cout"] * 2
+            us = sum(a.elapsed_time(b) for a, b in ev[lname]) / passes * 1e3
+            g = groups.setdefault(kname, dict(kernel=kname, launches_per_step=0, flops=0, bytes=0, us=0.0))
+            g["launches_per_step"] += 1
+            g["flops"] += f
+            g["bytes"] += byts
+            g["us"] += us
+        # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+        # runs, FETCH_SIZE doubled as the gfx950 note prescribes: tools/pmc_traffic.py); null when the file is absent
+        traffic, traffic_src, pmc_by_kernel = None, None, {}
+        for tag in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_b%d.json" % (tag, B))
+            if os.path.exists(tpath):
+                rows_t = [r for r in json.load(open(tpath)) if r["kernel"].startswith("sparse_conv")]
+                passes_t = max(1, min(r["launches"] for r in rows_t))
+                tot_b = sum((r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] / passes_t for r in rows_t)
+                n_l = sum(r["launches"] / passes_t for r in rows_t)
+                traffic, traffic_src = round(tot_b / n_l), "profiles/" + os.path.basename(tpath)
+                for r in rows_t:
+                    pmc_by_kernel[r["kernel"]] = round(r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
+                break
+
+        def pmc_for(kname):     # the PMC file keys kernels by their (mangled or demangled) name: match name + the two channel counts
+            base, ch = kname.split("<")[0], kname.split("<")[1].rstrip(">").split(",")[1:]
+            for k, v in pmc_by_kernel.items():
+                if base in k and ("Li%sELi%sE" % tuple(ch) in k or ", %s, %s," % tuple(ch) in k):
+                    return v
+            return None
+
+        per_kernel = []
+        for g in sorted(groups.values(), key=lambda g: -g["us"]):
+            n = g["launches_per_step"]
+            per_kernel.append({"kernel": g["kernel"], "launches_per_step": n, "flops_per_launch": int(g["flops"] / n),
+                               "avg_us": round(g["us"] / n, 1), "tflops": round(g["flops"] / (g["us"] * 1e-6) / 1e12, 1),
+                               "frac": round(g["flops"] / (g["us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "alg_bytes_per_launch": int(g["bytes"] / n),
+                               "alg_GBps": round(g["bytes"] / (g["us"] * 1e-6) / 1e9), "pmc_bytes_per_launch": pmc_for(g["kernel"])})
+        dom = per_kernel[0]
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "sparse_conv_slab_stream_kernel + sparse_conv_slab_kernel + sparse_conv_w32_kernel (%d conv launches/step)" % conv_launches,
-                    "flops_per_step": flops, "ms_per_step": round(conv_ms, 4)}
+                    "basis": "serial: one stream, HIP events around each conv launch of the same plan, %d passes after the timed region; "
+                             "frac = sum of algorithmic flops / sum of those durations (all %d conv launches of a step)" % (passes, conv_launches),
+                    "kernel": "all sparse-conv launches of a step; dominant: %s" % dom["kernel"],
+                    "dominant": {"kernel": dom["kernel"], "achieved": dom["tflops"], "frac": dom["frac"], "avg_us": dom["avg_us"],
+                                 "launches_per_step": dom["launches_per_step"]},
+                    "flops_per_step": flops, "ms_per_step": round(conv_ms, 4), "per_kernel": per_kernel}
         # the HBM-bound stages against the 8 TB/s roof, ALGORITHMIC bytes over the stage's own launch time
         n_pts = sum(int(f.shape[0]) for f in frames[:B])
         m0 = rows[0]
@@ -339,9 +419,11 @@ def main():
                "rulebook": {"bytes": rule_bytes, "GBps": round(rule_bytes / (rule_ms * 1e-3) / 1e9, 1)}}
         cpu = None
         if args.cpu_frames > 0 and world == 1:     # reported at N = 1 only
-            v, threads, sample = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(),
-                                              counts.cpu().numpy())
+            v, threads, sample, single = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(),
+                                                      counts.cpu().numpy(), args.cpu_single_frames)
             cpu = {"value": round(v, 4), "unit": "frames/s", "cores": threads, "kind": "port", "sample": sample}
+            if single is not None:
+                cpu["value_1_thread"] = round(single, 4)
         value = world * B * args.steps / elapsed
         out = {
             "metric": "frames/sec voxelize+sparse backbone+NMS (nuScenes CenterPoint)",
@@ -351,9 +433,9 @@ def main():
             "config": {"workload": "CenterPoint nuScenes 10-sweep 300k pts/frame, 0.075 m voxels, VoxelResBackBone8x, "
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
-                       "hip_graph": graph is not None, "streams": 1 if (args.no_overlap or args.graph) else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
+                       "hip_graph": graph is not None, "streams": 1 if args.no_overlap else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
                        "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "geo_after": args.geo_after, "rows_per_level": rows},
-            "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu,
+            "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu, "checked": checked,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
                        "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},
         }

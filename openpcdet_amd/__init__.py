@@ -9,10 +9,11 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_as_spconv(also_torch_scatter=False):
+def install_as_spconv(also_torch_scatter=True):
     """Register this package's stand-ins under the module names pcdet imports: `spconv`, `spconv.pytorch`,
     `spconv.utils`, `spconv.constants`, `cumm.tensorview` (pcdet/utils/spconv_utils.py:3-10,
-    pcdet/datasets/processor/data_processor.py:9-13,19-27).  Call before importing pcdet."""
+    pcdet/datasets/processor/data_processor.py:9-13,19-27) and, unless also_torch_scatter is False, `torch_scatter`
+    (scatter_mean / scatter_max, pcdet/models/backbones_3d/vfe/dynamic_*_vfe.py:5-9).  Call before importing pcdet."""
     import types
 
     from . import spconv as sp
@@ -39,4 +40,9 @@ def install_as_spconv(also_torch_scatter=False):
     cumm.tensorview = tv
     sys.modules.setdefault("cumm", cumm)
     sys.modules.setdefault("cumm.tensorview", tv)
+    if also_torch_scatter:
+        from . import scatter
+        ts = types.ModuleType("torch_scatter")
+        ts.scatter_mean, ts.scatter_max = scatter.scatter_mean, scatter.scatter_max
+        sys.modules.setdefault("torch_scatter", ts)
     return sp

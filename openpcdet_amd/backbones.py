@@ -150,6 +150,32 @@ class VoxelResBackBone8x(_Backbone8x):
     RES = True
 
 
+class _SegmentSum(torch.autograd.Function):
+    """zeros(m, C).index_add_(0, inv, feats) through pvx_scatter_sum (rows with inv < 0 are skipped); backward = grad[inv]."""
+
+    @staticmethod
+    def forward(ctx, feats, inv, m):
+        from . import _lib
+        L = _lib.lib()
+        dev = feats.device
+        n, c = feats.shape
+        with torch.cuda.device(dev):
+            summed = torch.empty((m, c), dtype=feats.dtype, device=dev)
+            ws2 = _lib.workspace(L.pvx_scatter_sum_workspace_bytes(m, c), dev)
+            _lib.check(L.pvx_scatter_sum(_lib.ptr(feats), _lib.DTYPE_CODE[feats.dtype], _lib.ptr(inv), n, None, c, m, _lib.ptr(summed),
+                                         _lib.ptr(ws2), ws2.numel(), _lib.stream()), "pvx_scatter_sum")
+        ctx.save_for_backward(inv)
+        ctx.n = n
+        return summed
+
+    @staticmethod
+    def backward(ctx, grad):
+        (inv,) = ctx.saved_tensors
+        idx = inv[:ctx.n].long()
+        g = grad[idx.clamp(min=0)]
+        return g * (idx >= 0).unsqueeze(1).to(g.dtype), None, None
+
+
 def unique_sites_sum(features, indices, spatial_shape, batch_size):
     """torch.unique(indices, dim=0, return_inverse=True) + zeros.index_add_(0, inverse, features) for coordinate rows
     (spconv_backbone_voxelnext.py:154-156) -> (unique indices in ascending row order, summed features)."""
@@ -176,10 +202,7 @@ def unique_sites_sum(features, indices, spatial_shape, batch_size):
         _lib.check(L.pvx_unique_sites(_lib.ptr(coords4), n, None, batch_size, c_shape, _lib.ptr(index), n, _lib.ptr(out4),
                                       _lib.ptr(inv), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()), "pvx_unique_sites")
         m = int(num.item())
-        summed = torch.empty((m, c), dtype=feats.dtype, device=dev)
-        ws2 = _lib.workspace(L.pvx_scatter_sum_workspace_bytes(m, c), dev)
-        _lib.check(L.pvx_scatter_sum(_lib.ptr(feats), _lib.DTYPE_CODE[feats.dtype], _lib.ptr(inv), n, None, c, m, _lib.ptr(summed),
-                                     _lib.ptr(ws2), ws2.numel(), _lib.stream()), "pvx_scatter_sum")
+        summed = _SegmentSum.apply(feats, inv, m)
     uniq = out4[:m] if nd == 3 else out4[:m][:, [0, 2, 3]].contiguous()
     return uniq, summed
 

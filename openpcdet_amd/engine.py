@@ -216,7 +216,7 @@ class HotPathEngine:
             name = "conv%d_%dx%d_k%d" % (len(self.conv_records), cin, cout, kvol)
             self.ops.append((name, lambda st, a=args: _lib.check(L.pvx_sparse_conv_fwd(*a, st), "pvx_sparse_conv_fwd")))
             self.conv_records.append(dict(name=name, cin=cin, cin_real=conv.in_channels, cout=cout, kvol=kvol, nbr=nbr,
-                                          level_out=level_out, subm=conv.subm))
+                                          level_in=level_in, level_out=level_out, subm=conv.subm, residual=residual_buf is not None))
             return out, cout
 
         # site index of the input level

@@ -65,6 +65,32 @@ def _shape_list(spatial_shape):
     return [int(x) for x in np.asarray(spatial_shape).reshape(-1).tolist()]
 
 
+class _DenseFunction(torch.autograd.Function):
+    """features [N, C] at coords [N, 4] (b, z, y, x) -> dense [B, C, D, H, W] through pvx_sparse_to_dense; backward = the rows
+    of the dense gradient at the same cells (what autograd derives for the reference's indexed assignment)."""
+
+    @staticmethod
+    def forward(ctx, feats, coords, batch_size, shape3):
+        f = feats.contiguous()
+        L = _lib.lib()
+        dev = f.device
+        c = f.shape[1]
+        out = torch.empty((batch_size, c, *shape3), dtype=f.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.pvx_sparse_to_dense(_lib.ptr(f), _lib.ptr(coords), f.shape[0], None, c, _lib.DTYPE_CODE[f.dtype],
+                                             batch_size, _lib.int3(list(shape3)), _lib.ptr(out), _lib.stream()),
+                       "pvx_sparse_to_dense")
+        ctx.save_for_backward(coords)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (coords,) = ctx.saved_tensors
+        ix = coords.long()
+        g = grad_out[ix[:, 0], :, ix[:, 1], ix[:, 2], ix[:, 3]]
+        return g.contiguous(), None, None, None
+
+
 class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None, voxel_num=None, indice_dict=None,
                  benchmark=False, permanent_thrust_allocator=False, enable_timer=False, force_algo=None):
@@ -177,21 +203,13 @@ class SparseConvTensor:
 
     # ---- dense() --------------------------------------------------------------------------------------
     def dense(self, channels_first=True):
-        """[B, C, *spatial] (height_compression.py:22); channels_first=False gives [B, *spatial, C]."""
+        """[B, C, *spatial] (height_compression.py:22); channels_first=False gives [B, *spatial, C].  Differentiable with
+        respect to the features, as spconv's: the backward is the gather of the dense gradient at the active sites."""
         f = self._features
         if not f.is_cuda:
             raise RuntimeError("SparseConvTensor.dense() runs on the GPU only (no CPU fallback)")
-        f = f.contiguous()
-        L = _lib.lib()
-        dev = f.device
-        c = f.shape[1]
         shape3 = self._shape3()
-        out = torch.empty((self.batch_size, c, *shape3), dtype=f.dtype, device=dev)
-        coords = self._coords4()
-        with torch.cuda.device(dev):
-            _lib.check(L.pvx_sparse_to_dense(_lib.ptr(f), _lib.ptr(coords), f.shape[0], None, c, _lib.DTYPE_CODE[f.dtype],
-                                             self.batch_size, _lib.int3(shape3), _lib.ptr(out), _lib.stream()),
-                       "pvx_sparse_to_dense")
+        out = _DenseFunction.apply(f, self._coords4(), self.batch_size, tuple(shape3))
         if len(self.spatial_shape) == 2:
             out = out[:, :, 0]
         if not channels_first:

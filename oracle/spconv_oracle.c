@@ -206,6 +206,15 @@ long long orc_count_pairs(const int* nbr, int K, int n_out) {
     return p;
 }
 
+/* threads for the next orc_sparse_conv_fwd calls (bench.py's cpu_baseline times 1 and all) */
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* SparseConvTensor.dense(): [B, C, D, H, W] from rows (height_compression.py:22) */
 void orc_dense(const float* feat, const int* coords, int n, int c, int batch, const int* shape, float* out) {
     const size_t vol = (size_t)shape[0] * shape[1] * shape[2];

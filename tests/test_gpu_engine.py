@@ -55,14 +55,17 @@ def module_path(net, frames, cfg, dev, dtype):
     return bd
 
 
-def oracle_chain(net, frames, cfg):
-    """CPU oracle end to end (fp32): returns per-stage (coords, feats) and the dense tensor."""
+def oracle_chain(net, frames, cfg, round_bf16=False):
+    """CPU oracle end to end (fp32): returns per-stage (coords, feats) and the dense tensor.  round_bf16: the operands the
+    bf16 plan starts from (input features and conv weights) are rounded to bf16 first; all arithmetic stays fp32."""
     feats, coords = [], []
     for b, pts in enumerate(frames):
         vox, czyx, num, _ = loader.voxelize_hard(pts, cfg["voxel"], cfg["range"], cfg["T"], cfg["max_voxels"])
         feats.append(loader.mean_vfe(vox, num))
         coords.append(np.concatenate([np.full((czyx.shape[0], 1), b, np.int32), czyx], 1))
     x, c = np.concatenate(feats), np.concatenate(coords)
+    if round_bf16:
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
     shape, B = list(net.sparse_shape), len(frames)
     books = {}
 
@@ -72,7 +75,8 @@ def oracle_chain(net, frames, cfg):
 
     def conv(f, cv, key):
         nonlocal c, shape
-        w = cv.weight.detach().float().cpu().numpy()
+        w = cv.weight.detach().float().cpu()
+        w = (w.to(torch.bfloat16).float() if round_bf16 else w).numpy()
         b = cv.bias.detach().float().cpu().numpy() if cv.bias is not None else None
         if cv.subm:
             if key not in books:
@@ -175,6 +179,94 @@ def test_engine_bf16_full_frame_and_graph_replay(cuda_device):
     assert torch.equal(eng.dense.view_as(eager), eager)
     flops, per = eng.conv_flops()
     assert flops > 0 and len(per) == 21
+
+
+def test_engine_bf16_full_frame_vs_oracle(cuda_device):
+    """the bf16 plan exactly as bench.py runs it (default sort_input=True: rows in key order, slab kernels
+    with in-window LDS reads, BatchNorm folded into the epilogue) on a FULL 300k-point nuScenes frame, every stage against
+    the CPU oracle chain (fp32 arithmetic on bf16-rounded inputs and weights).  Bars: coordinates bit-exact, features
+    rel-L2 <= 1e-2 (north_star's bf16 tolerance)."""
+    cfg = synth.CONFIGS["nuscenes_centerpoint"]
+    frames = [synth.config_cloud("nuscenes_centerpoint", 3)]
+    assert frames[0].shape[0] >= 290000
+    net = make_backbone(backbones.VoxelResBackBone8x, cfg, 11, cuda_device)
+    eng = engine.HotPathEngine(net, 1, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
+                               dtype=torch.bfloat16, device=cuda_device, level_capacity_factor=2.0)
+    assert eng.sort_input
+    eng.load_points([torch.from_numpy(frames[0]).to(cuda_device)])
+    bev = eng.forward()
+    torch.cuda.synchronize()
+    assert not eng.overflowed()
+    outs, want = oracle_chain(net, frames, cfg, round_bf16=True)
+    errs = []
+    for i in range(6):
+        gc, gf = eng.stage_output(i)
+        oc, of = outs[i]
+        assert np.array_equal(gc.cpu().numpy(), oc), "stage %d coordinates" % i
+        errs.append(rel_l2(gf.float().cpu().numpy(), of))
+    print("bf16 plan vs oracle, rel-L2 per stage:", ["%.4f" % e for e in errs])
+    assert max(errs) <= 1e-2, errs
+    assert rel_l2(bev.float().cpu().numpy().reshape(want.shape), want) <= 1e-2
+
+
+def test_engine_multistream_graph_replay(cuda_device):
+    """The plan's overlapped schedule -- geometry on its own stream, forked from and joined to the conv stream through events,
+    plus the batched NMS on a third stream -- captured in ONE HIP graph and replayed on new inputs: bit-identical to the eager
+    single-stream launch sequence (`bench.py --graph` captures exactly this)."""
+    cfg = synth.CONFIGS["nuscenes_centerpoint"]
+    frames = [synth.config_cloud("nuscenes_centerpoint", 3 + i, n_points=60000) for i in range(3)]
+    net = make_backbone(backbones.VoxelResBackBone8x, cfg, 11, cuda_device)
+    eng = engine.HotPathEngine(net, 2, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], 60000,
+                               dtype=torch.bfloat16, device=cuda_device)
+    S, cap = 4, 300
+    rng = np.random.default_rng(5)
+    nms = engine.BatchedNMS(S, cap, 0.2, 83, device=cuda_device)
+    boxes = torch.from_numpy(np.c_[rng.uniform(-20, 20, (S * cap, 2)), rng.uniform(-1, 1, S * cap), rng.uniform(0.5, 4, (S * cap, 3)),
+                                   rng.uniform(-3, 3, S * cap)].astype(np.float32).reshape(S, cap, 7)).to(cuda_device)
+    scores = torch.from_numpy(rng.permutation(S * cap).astype(np.float32).reshape(S, cap)).to(cuda_device)
+    counts = torch.tensor([300, 17, 0, 256], dtype=torch.int32, device=cuda_device)
+    nms_stream = torch.cuda.Stream(device=cuda_device)
+    out = {}
+
+    def step():
+        cur = torch.cuda.current_stream(cuda_device)
+        nms_stream.wait_stream(cur)
+        with torch.cuda.stream(nms_stream):
+            out["sel"], out["num"] = nms(boxes, scores, counts)
+        eng.forward(overlap=True)
+        cur.wait_stream(nms_stream)
+
+    def load(pair):
+        eng.load_points([torch.from_numpy(frames[i]).to(cuda_device) for i in pair])
+
+    # eager references for two different batches, single stream
+    want = []
+    for pair in ((0, 1), (2, 0)):
+        load(pair)
+        eng.forward(overlap=False)
+        sel, num = nms(boxes, scores, counts)
+        torch.cuda.synchronize()
+        want.append((eng.dense.clone(), sel.clone(), num.clone(), eng.level_rows()))
+    load((0, 1))
+    s = torch.cuda.Stream(device=cuda_device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()                                  # the overlapped schedule once eagerly: streams and events exist before the capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.dense, want[0][0])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    for k, pair in enumerate(((0, 1), (2, 0), (0, 1))):
+        load(pair)
+        eng.dense.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        d, sel, num, rows = want[k % 2]
+        assert eng.level_rows() == rows
+        assert torch.equal(eng.dense, d), "replay %d differs from the eager launch sequence" % k
+        assert torch.equal(out["num"], num) and torch.equal(out["sel"], sel)
 
 
 def test_batched_nms_plan_vs_oracle(cuda_device):
