@@ -381,12 +381,10 @@ def main():
                     pmc_by_kernel[r["kernel"]] = round(r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"])
                 break
 
-        def pmc_for(kname):     # the PMC file keys kernels by their (mangled or demangled) name: match name + the two channel counts
-            base, ch = kname.split("<")[0], kname.split("<")[1].rstrip(">").split(",")[1:]
-            for k, v in pmc_by_kernel.items():
-                if base in k and ("Li%sELi%sE" % tuple(ch) in k or ", %s, %s," % tuple(ch) in k):
-                    return v
-            return None
+        def pmc_for(kname):     # tools/pmc_traffic.py keys: sparse_conv_slab<cin=64,cout=64> / sparse_conv_w32<cin=..,cout=..>
+            ch = kname.split("<")[1].rstrip(">").split(",")[1:]
+            kind = "sparse_conv_slab" if "slab" in kname else ("sparse_conv_v3" if "v3" in kname else "sparse_conv_w32")
+            return pmc_by_kernel.get("%s<cin=%s,cout=%s>" % (kind, ch[0], ch[1]))
 
         per_kernel = []
         for g in sorted(groups.values(), key=lambda g: -g["us"]):
