@@ -68,12 +68,13 @@ __device__ __forceinline__ s16x8 read_operand(const unsigned char* tile, int lan
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// one wave per workgroup; unit = blockIdx.x = chunk * K + k
-template <typename E, int CIN, int COUT>
+// one wave per workgroup; unit = blockIdx.x = chunk * K + k.  RAGGED: the input rows hold cin_rt < CIN = 32 channels (the
+// backbone's first layer: 4..6 point features), gathered element by element into the zero-padded 32-channel tile.
+template <typename E, int CIN, int COUT, bool RAGGED>
 __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ feat_in, int n_in, const E* __restrict__ gout,
                                                          const int* __restrict__ nbr, int kvol, int n_out_cap,
                                                          const int* __restrict__ n_out_dev, int rows_per_chunk,
-                                                         float* __restrict__ partial) {
+                                                         float* __restrict__ partial, int cin_rt) {
     typedef TileGeo<COUT> GO;
     typedef TileGeo<CIN> GI;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GO::BYTES + GI::BYTES];
@@ -112,22 +113,36 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ fe
             if (row < kTileRows && r0 + row < row_end)
                 vo[it] = *reinterpret_cast<const uint4*>(gout + (size_t)(r0 + row) * COUT + cc * 8);
         }
+        if constexpr (RAGGED) {
+            // 32 rows x cin_rt two-byte elements, lane-strided; columns >= cin_rt keep the zeros written before the loop
+            const int total = kTileRows * cin_rt;
+            for (int e = lane; e < total; e += 64) {
+                const int row = e / cin_rt, ci = e - row * cin_rt;
+                const int src = __shfl(my_src, row);
+                unsigned short v = 0;
+                if (src >= 0) v = reinterpret_cast<const unsigned short*>(feat_in)[(size_t)src * cin_rt + ci];
+                *reinterpret_cast<unsigned short*>(tile_i + row * GI::STRIDE + ci * 2) = v;
+            }
+        } else {
 #pragma unroll
-        for (int it = 0; it < IT_I; it++) {
-            const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
-            const int src = __shfl(my_src, row & 31);
-            vi[it] = make_uint4(0, 0, 0, 0);
-            if (row < kTileRows && src >= 0) vi[it] = *reinterpret_cast<const uint4*>(feat_in + (size_t)src * CIN + cc * 8);
+            for (int it = 0; it < IT_I; it++) {
+                const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
+                const int src = __shfl(my_src, row & 31);
+                vi[it] = make_uint4(0, 0, 0, 0);
+                if (row < kTileRows && src >= 0) vi[it] = *reinterpret_cast<const uint4*>(feat_in + (size_t)src * CIN + cc * 8);
+            }
         }
 #pragma unroll
         for (int it = 0; it < IT_O; it++) {
             const int c = it * 64 + lane, row = c / GO::CHUNKS, cc = c % GO::CHUNKS;
             if (row < kTileRows) *reinterpret_cast<uint4*>(tile_o + row * GO::STRIDE + cc * 16) = vo[it];
         }
+        if constexpr (!RAGGED) {
 #pragma unroll
-        for (int it = 0; it < IT_I; it++) {
-            const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
-            if (row < kTileRows) *reinterpret_cast<uint4*>(tile_i + row * GI::STRIDE + cc * 16) = vi[it];
+            for (int it = 0; it < IT_I; it++) {
+                const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
+                if (row < kTileRows) *reinterpret_cast<uint4*>(tile_i + row * GI::STRIDE + cc * 16) = vi[it];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -149,7 +164,8 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ fe
     }
 
     // D[m][n]: n = lane & 31, m = 8 * (reg >> 2) + 4 * (lane >> 5) + (reg & 3)
-    float* __restrict__ dst = partial + ((size_t)chunk * kvol + k) * (size_t)(COUT * CIN);
+    const int cin = RAGGED ? cin_rt : CIN;
+    float* __restrict__ dst = partial + ((size_t)chunk * kvol + k) * (size_t)(COUT * cin);
 #pragma unroll
     for (int to = 0; to < GO::TILES; to++)
 #pragma unroll
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ fe
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int co = 32 * to + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), ci = 32 * ti + (lane & 31);
-                if (co < COUT && ci < CIN) dst[(size_t)co * CIN + ci] = acc[to][ti][j];
+                if (co < COUT && ci < cin) dst[(size_t)co * cin + ci] = acc[to][ti][j];
             }
 }
 
@@ -241,10 +257,14 @@ int rows_per_chunk_for(int n_out, int kvol) {
 }
 
 #define PVX_WGRAD_SHAPES X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 128) X(128, 128)
+#define PVX_WGRAD_RAGGED_COUT X(16) X(32) X(64)      // first layer: cin < 32 point features, any of these widths out
 
 bool mfma_shape(int cin, int cout) {
 #define X(CI, CO) if (cin == CI && cout == CO) return true;
     PVX_WGRAD_SHAPES
+#undef X
+#define X(CO) if (cin < 32 && cout == CO) return true;
+    PVX_WGRAD_RAGGED_COUT
 #undef X
     return false;
 }
@@ -254,12 +274,21 @@ int launch_mfma(const void* feat_in, int n_in, int cin, const void* gout, const 
                 int cout, int rpc, float* partial, unsigned units, hipStream_t st) {
 #define X(CI, CO)                                                                                                              \
     if (cin == CI && cout == CO) {                                                                                             \
-        hipLaunchKernelGGL((wgrad_mfma_kernel<E, CI, CO>), dim3(units), dim3(64), 0, st, (const E*)feat_in, n_in, (const E*)gout,  \
-                           nbr, kvol, n_out, n_out_dev, rpc, partial);                                                         \
+        hipLaunchKernelGGL((wgrad_mfma_kernel<E, CI, CO, false>), dim3(units), dim3(64), 0, st, (const E*)feat_in, n_in,          \
+                           (const E*)gout, nbr, kvol, n_out, n_out_dev, rpc, partial, CI);                                     \
         PVX_CHECK_LAUNCH();                                                                                                    \
         return PVX_OK;                                                                                                         \
     }
     PVX_WGRAD_SHAPES
+#undef X
+#define X(CO)                                                                                                                  \
+    if (cin < 32 && cout == CO) {                                                                                              \
+        hipLaunchKernelGGL((wgrad_mfma_kernel<E, 32, CO, true>), dim3(units), dim3(64), 0, st, (const E*)feat_in, n_in,           \
+                           (const E*)gout, nbr, kvol, n_out, n_out_dev, rpc, partial, cin);                                    \
+        PVX_CHECK_LAUNCH();                                                                                                    \
+        return PVX_OK;                                                                                                         \
+    }
+    PVX_WGRAD_RAGGED_COUT
 #undef X
     return PVX_ERR_INVALID;
 }

@@ -2,6 +2,7 @@
 (dgrad = implicit GEMM over the inverse rulebook, wgrad = pvx_sparse_conv_wgrad, through the module API's autograd) against
 torch autograd on the CPU over the ORACLE's rulebooks, where a sparse conv is written as the reference's "native"
 gather -> GEMM -> scatter-add per kernel offset.  Bar (north_star): rel-L2 <= 1e-3 fp32, <= 1e-2 bf16 / fp16."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -291,3 +292,58 @@ def test_grads_flow_through_dense_scatter_and_bev_out(cuda_device):
     u, inv = np.unique(c3[:, [0, 2, 3]], axis=0, return_inverse=True)
     assert np.array_equal(uniq.cpu().numpy(), u)
     assert np.allclose(t3.grad.cpu().numpy(), up3[inv.reshape(-1)], rtol=0, atol=0)
+
+
+def test_ddp_syncbn_world1_training_step(cuda_device):
+    """tools/train.py:130-131,162: the module API under SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel over RCCL
+    (world size 1 here; the world-size-2 gradient average is tests/test_dist_gloo.py): a bf16 autocast step through
+    VoxelResBackBone8x -> HeightCompression yields the same loss and parameter gradients as the unwrapped module."""
+    import copy
+    import torch.distributed as dist
+    from openpcdet_amd import voxelize
+    cfg = synth.CONFIGS["waymo_centerpoint"]
+    torch.manual_seed(17)
+    grid = loader.voxel_grid_size(cfg["voxel"], cfg["range"])
+    net = backbones.VoxelResBackBone8x(input_channels=cfg["C"], grid_size=np.array(grid)).to(cuda_device).train()
+    gen = voxelize.PointToVoxel(cfg["voxel"], cfg["range"], cfg["C"], cfg["max_voxels"], cfg["T"])
+    feats, coords = [], []
+    for b, s in enumerate((51, 52)):
+        o = gen.run(torch.from_numpy(synth.config_cloud("waymo_centerpoint", s, n_points=20000)).to(cuda_device), want_voxels=False, want_mean=True)
+        m = int(o["num_voxels"].item())
+        feats.append(o["mean"][:m])
+        coords.append(torch.cat([torch.full((m, 1), b, dtype=torch.int32, device=cuda_device), o["coords"][:m]], 1))
+    feats, coords = torch.cat(feats), torch.cat(coords)
+    hc = backbones.HeightCompression()
+
+    def run(model):
+        for p in model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            bev = hc(model({"voxel_features": feats, "voxel_coords": coords, "batch_size": 2}))["spatial_features"]
+            loss = (bev.float() ** 2).mean()
+        loss.backward()
+        return float(loss.item())
+
+    loss0 = run(net)
+    want = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+    created = not dist.is_initialized()
+    if created:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(cuda_device))
+    try:
+        wrapped = torch.nn.SyncBatchNorm.convert_sync_batchnorm(copy.deepcopy(net))
+        assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in wrapped.modules())
+        ddp = torch.nn.parallel.DistributedDataParallel(wrapped, device_ids=[torch.device(cuda_device).index or 0])
+        loss1 = run(ddp)
+        got = {k: p.grad for k, p in wrapped.named_parameters()}
+        assert set(got) == set(want)
+        assert abs(loss1 - loss0) <= 2e-2 * abs(loss0), (loss0, loss1)
+        for k in want:
+            assert got[k] is not None, k
+            if not k.endswith(("conv1.bias", "conv2.bias")):      # zero-gradient biases ahead of BatchNorm: rounding noise only
+                assert rel_l2(got[k].float().cpu().numpy(), want[k].float().cpu().numpy()) <= 5e-2, k
+        torch.optim.AdamW(wrapped.parameters(), lr=1e-3).step()
+    finally:
+        if created:
+            dist.destroy_process_group()
