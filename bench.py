@@ -116,13 +116,16 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--no-vox-ahead", action="store_true",
                     help="voxelize each batch inside its own step instead of one step ahead, beside the previous batch's rulebooks")
-    ap.add_argument("--geo-after", type=int, default=3,
-                    help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 3 measured best "
-                         "for this backbone: profiles/r01_d_conv_variants.txt)")
+    ap.add_argument("--geo-after", type=int, default=9,
+                    help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 8..11 measured "
+                         "best for this backbone with the in-kernel NMS front end: profiles/r02_schedule_sweep.txt)")
     ap.add_argument("--geometry-cus", type=int, default=0,
                     help="CUs reserved for the geometry / NMS streams (CU-masked streams; 0 = shared CUs, priority streams)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
+    ap.add_argument("--nms-stream", default="own", choices=("own", "vox"), help="stream of the NMS launches: its own, or the voxelizer's")
+    ap.add_argument("--nms-first", action="store_true", help="issue the NMS launches before the plan's (diagnostic)")
+    ap.add_argument("--nms-after", type=int, default=14, help="hold the NMS back until this conv layer of the batch has been reached (0 = do not)")
     ap.add_argument("--graph", action="store_true", help="capture one plan's step -- convs, geometry stream and NMS stream forked from and joined "
                     "to the capturing stream -- in a HIP graph and replay it.  The default launches eagerly (the step is device-bound) and "
                     "alternates two plans, whose cross-step event waits a single capture cannot hold")
@@ -225,34 +228,39 @@ def main():
     vox_ahead = pipelined and not args.no_vox_ahead
     vox_stream = torch.cuda.Stream(device=dev) if vox_ahead else None
 
+    nms_on = vox_stream if (vox_ahead and args.nms_stream == "vox") else nms_stream
+
     def step(i):
         if pipelined:
             plan = eng if i % 2 == 0 else eng2
             cur = torch.cuda.current_stream(dev)
-            if vox_ahead and args.geo_after > 0:
-                # as below, but the next batch's geometry is held back until a chosen conv layer of this batch has been reached
-                nxt = eng2 if i % 2 == 0 else eng
-                with torch.cuda.stream(nms_stream):
+            def run_nms():
+                with torch.cuda.stream(nms_on):   # its inputs are loaded on its own stream: nothing to wait for
+                    if args.nms_after > 0:
+                        nms_on.wait_event(plan.mark2)   # start beside a chosen conv layer of this batch
                     load_boxes(i)
                     result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
-                plan.forward(overlap=True, pipelined=True, prevoxelized=True, mark_after=args.geo_after)
+            if args.nms_first:
+                run_nms()
+            nxt = eng2 if i % 2 == 0 else eng
+            if vox_ahead and args.geo_after > 0:
+                # batch i was voxelized during step i-1; the next batch's voxelizer is held back until a chosen conv layer of
+                # this batch has been reached
+                plan.forward(overlap=True, pipelined=True, prevoxelized=True, mark_after=args.geo_after, mark2_after=args.nms_after)
                 nxt.voxelize_ahead(vox_stream, load=lambda: load_points(i + 1, nxt), after=plan.mark)
-                cur.wait_stream(nms_stream)
-                return
-            if vox_ahead:
-                # batch i was voxelized during step i-1; batch i+1 is voxelized now, on its own stream, beside batch i's rulebooks
-                nxt = eng2 if i % 2 == 0 else eng
-                nxt.voxelize_ahead(vox_stream, load=lambda: load_points(i + 1, nxt))
             else:
-                geo = plan.geometry_stream()
-                with torch.cuda.stream(geo):
-                    geo.wait_event(plan._done)      # the plan's previous batch has left these buffers
-                    load_points(i, plan)
-            with torch.cuda.stream(nms_stream):   # its inputs are loaded on its own stream: nothing to wait for
-                load_boxes(i)
-                result["sel"], result["num"] = nms(s_boxes, s_scores, s_counts)
-            plan.forward(overlap=True, pipelined=True, prevoxelized=vox_ahead)
-            cur.wait_stream(nms_stream)
+                if vox_ahead:
+                    # batch i+1 is voxelized now, on its own stream, beside batch i's rulebooks
+                    nxt.voxelize_ahead(vox_stream, load=lambda: load_points(i + 1, nxt))
+                else:
+                    geo = plan.geometry_stream()
+                    with torch.cuda.stream(geo):
+                        geo.wait_event(plan._done)      # the plan's previous batch has left these buffers
+                        load_points(i, plan)
+                plan.forward(overlap=True, pipelined=True, prevoxelized=vox_ahead, mark2_after=args.nms_after)
+            if not args.nms_first:
+                run_nms()
+            cur.wait_stream(nms_on)
             return
         load(i)
         if graph is not None:

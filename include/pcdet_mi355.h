@@ -81,6 +81,19 @@ int pvx_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, 
 int pvx_nms_batched(const float* boxes, const int* counts, int segments, int n_cap, float thresh, int normal,
                     int64_t* keep, int* num_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* class_agnostic_nms (pcdet/models/model_utils/model_nms_utils.py:6-25) for `segments` problems in three launches:
+ * score threshold (:8-11; pass -INFINITY for none), top-pre_max by descending score (:15, ties by ascending index;
+ * pre_max <= 0 = n_cap), box gather (:16), NMS (:17-19, normal as for pvx_nms), keep[:post_max] mapped back to the
+ * caller's box indices (:20,23-24).  boxes is [segments, n_cap, box_stride >= 7] (columns 0..6 are used), scores
+ * [segments, n_cap], counts[s] (device int32, may be NULL = n_cap) the leading valid boxes of segment s.
+ * selected is [segments, post_max] int64 (entries at and beyond num_selected[s] repeat the best-scored index),
+ * num_selected [segments].  n_cap <= 16384 (one problem's sort keys live in one CU's LDS; PVX_ERR_RANGE beyond:
+ * sort on the caller's side and use pvx_nms_batched).  No host synchronisation. */
+size_t pvx_nms_select_workspace_bytes(int n_cap, int segments);
+int pvx_nms_select_batched(const float* boxes, int box_stride, const float* scores, const int* counts, int segments,
+                           int n_cap, float score_thresh, int pre_max, float nms_thresh, int normal, int post_max,
+                           int64_t* selected, int* num_selected, void* workspace, size_t workspace_bytes, void* stream);
+
 /* pvx_nms for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc) and bring no workspace: the suppression mask lives in a static device array inside the library
  * (PVX_NMS_STATIC_MAX^2 / 8 bytes = 2 MiB per GPU the library runs on, held until the process ends).  Calls no

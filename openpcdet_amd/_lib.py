@@ -33,6 +33,9 @@ SIGNATURES = {
     "pvx_nms": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
+    "pvx_nms_select_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "pvx_nms_select_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_float, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_nms_static": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev_cpu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

@@ -9,7 +9,10 @@
 //  * the greedy scan runs on the device in one workgroup per problem, so neither the N x N/64 mask nor the
 //    keep list crosses PCIe (the reference copies the whole mask D2H and loops on the host,
 //    iou3d_nms.cpp:155-179);
-//  * many independent problems (heads x frames) go in one launch through a segment table.
+//  * many independent problems (heads x frames) go in one launch through a segment table;
+//  * pvx_nms_select_batched also does what surrounds the NMS call in class_agnostic_nms (model_nms_utils.py:6-25) on the
+//    device: score threshold, top-NMS_PRE_MAXSIZE by score (one LDS bitonic sort per problem), box gather, NMS,
+//    keep[:NMS_POST_MAXSIZE] mapped back to the caller's indices -- three launches, no torch kernels around them.
 // Build flags for this TU: -ffp-contract=off (see iou_core.h).
 #include <atomic>
 #include "pvx_common.h"
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restric
 __global__ __launch_bounds__(kBlock) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                            const int* __restrict__ counts, int n_host, int n_cap,
                                                            int cb_cap, long long* __restrict__ keep,
-                                                           int* __restrict__ num_keep) {
+                                                           int* __restrict__ num_keep, const int* __restrict__ order,
+                                                           long long* __restrict__ sel, int post_max) {
     __shared__ unsigned long long remv[kMaxColBlocks];
     __shared__ int kept_in_chunk[64];
     __shared__ int kept_count;
@@ -220,7 +224,81 @@ __global__ __launch_bounds__(kBlock) void nms_scan_kernel(const unsigned long lo
             remv[w] = acc;
         }
     }
-    if (tid == 0) num_keep[seg] = total;
+    if (!order) {
+        if (tid == 0) num_keep[seg] = total;
+        return;
+    }
+    // select epilogue (model_nms_utils.py:20): sel[j] = order[keep[j]] for j < min(kept, post_max); the unused tail of sel
+    // points at the best-scored box (order[0]) so that a gather through it stays in range
+    __syncthreads();                                      // seg_keep was written by wave 0 of this workgroup
+    const int* seg_order = order + (size_t)seg * n_cap;
+    const int lim = total < post_max ? total : post_max;
+    for (int j = tid; j < post_max; j += kBlock) sel[(size_t)seg * post_max + j] = seg_order[j < lim ? (int)seg_keep[j] : 0];
+    if (tid == 0) num_keep[seg] = lim;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Front end of one NMS problem per workgroup: keys = (score descending, index ascending) of the boxes with
+// index < counts[seg] and score >= score_thresh, bitonic-sorted in LDS (P = power of two >= n_cap keys of 8 bytes);
+// the best min(valid, pre_max) boxes are gathered in that order, `order` keeps their original indices.
+// NaN scores sort first, as torch.topk / sort treat them.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSortBlock = 1024;
+constexpr int kSortMaxKeys = 16384;                       // 128 KiB of the 160 KiB LDS
+
+__global__ __launch_bounds__(kSortBlock) void nms_sort_gather_kernel(const float* __restrict__ boxes, int box_stride,
+                                                                      const float* __restrict__ scores,
+                                                                      const int* __restrict__ counts, int n_cap, int P,
+                                                                      float score_thresh, int pre_max,
+                                                                      float* __restrict__ sorted_boxes, int* __restrict__ order,
+                                                                      int* __restrict__ eff_counts) {
+    extern __shared__ unsigned long long keys[];
+    __shared__ int n_valid;
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    int n = counts ? counts[seg] : n_cap;
+    n = n < 0 ? 0 : (n > n_cap ? n_cap : n);
+    if (tid == 0) n_valid = 0;
+    __syncthreads();
+    const bool has_thresh = score_thresh > -INFINITY;     // -inf (or NaN) = no threshold
+    int mine = 0;
+    for (int i = tid; i < P; i += kSortBlock) {
+        unsigned long long key = 0xffffffff00000000ull | (unsigned)i;
+        if (i < n) {
+            const float sc = scores[(size_t)seg * n_cap + i];
+            if (!has_thresh || sc >= score_thresh) {      // `box_scores >= score_thresh` (model_nms_utils.py:9): drops NaN too
+                unsigned u = __float_as_uint(sc);
+                u = (u >> 31) ? ~u : (u | 0x80000000u);   // monotone map of binary32 order onto unsigned order
+                if (sc != sc) u = 0xffffffffu;            // without a threshold NaN sorts first, as torch.topk places it
+                key = ((unsigned long long)(~u) << 32) | (unsigned)i;
+                mine++;
+            }
+        }
+        keys[i] = key;
+    }
+    if (mine) atomicAdd(&n_valid, mine);
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += kSortBlock) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    int eff = n_valid;
+    if (pre_max > 0 && eff > pre_max) eff = pre_max;
+    if (tid == 0) eff_counts[seg] = eff;
+    const float* seg_boxes = boxes + (size_t)seg * n_cap * box_stride;
+    float* seg_sorted = sorted_boxes + (size_t)seg * n_cap * 7;
+    int* seg_order = order + (size_t)seg * n_cap;
+    for (int i = tid; i < n_cap; i += kSortBlock) seg_order[i] = (int)(unsigned)(keys[i] & 0xffffffffull);
+    for (int e = tid; e < eff * 7; e += kSortBlock) {
+        const int i = e / 7, c = e - i * 7;
+        seg_sorted[e] = seg_boxes[(size_t)(unsigned)(keys[i] & 0xffffffffull) * box_stride + c];
+    }
 }
 
 int check_boxes(const float* a, int n, const float* b, int m, const float* out) {
@@ -276,7 +354,67 @@ static int nms_run(const float* boxes, const int* counts, int segments, int n_ca
         hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(segments), dim3(kBlock), 0, st, mask, counts, n_cap, n_cap, cb_cap,
-                       (long long*)keep, num_keep);
+                       (long long*)keep, num_keep, (const int*)nullptr, (long long*)nullptr, 0);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+static int sort_keys_for(int n_cap) {
+    int p = 64;
+    while (p < n_cap) p <<= 1;
+    return p;
+}
+
+extern "C" size_t pvx_nms_select_workspace_bytes(int n_cap, int segments) {
+    if (n_cap <= 0 || segments <= 0) return 256;
+    PvxSizer s;
+    s.take<unsigned long long>((size_t)segments * n_cap * PVX_CDIV(n_cap, 64));   // mask
+    s.take<long long>((size_t)segments * n_cap);                                 // keep
+    s.take<float>((size_t)segments * n_cap * 7);                                 // boxes in score order
+    s.take<int>((size_t)segments * n_cap);                                       // order
+    s.take<int>((size_t)segments);                                               // boxes that enter the NMS
+    return s.total();
+}
+
+extern "C" int pvx_nms_select_batched(const float* boxes, int box_stride, const float* scores, const int* counts, int segments,
+                                      int n_cap, float score_thresh, int pre_max, float nms_thresh, int normal, int post_max,
+                                      int64_t* selected, int* num_selected, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    if (segments < 0 || n_cap < 0 || post_max < 0 || box_stride < 7 || !num_selected) return PVX_ERR_INVALID;
+    if (segments == 0) return PVX_OK;
+    if (segments > 65535) return PVX_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_cap == 0 || post_max == 0) {
+        PVX_CHECK_HIP(hipMemsetAsync(num_selected, 0, sizeof(int) * segments, st));
+        if (post_max > 0 && selected) PVX_CHECK_HIP(hipMemsetAsync(selected, 0, sizeof(int64_t) * (size_t)segments * post_max, st));
+        return PVX_OK;
+    }
+    if (!boxes || !scores || !selected) return PVX_ERR_INVALID;
+    const int P = sort_keys_for(n_cap);
+    if (P > kSortMaxKeys) return PVX_ERR_RANGE;           // one problem's keys must fit one CU's LDS
+    const int cb_cap = PVX_CDIV(n_cap, 64);
+    PvxCarver ws(workspace, workspace_bytes);
+    unsigned long long* mask = ws.take<unsigned long long>((size_t)segments * n_cap * cb_cap);
+    long long* keep = ws.take<long long>((size_t)segments * n_cap);
+    float* sorted = ws.take<float>((size_t)segments * n_cap * 7);
+    int* order = ws.take<int>((size_t)segments * n_cap);
+    int* eff = ws.take<int>((size_t)segments);
+    if (!ws.ok() || !mask) return PVX_ERR_WORKSPACE;
+    const size_t lds = (size_t)P * sizeof(unsigned long long);
+    if (lds > 32 * 1024)      // per device and cheap: asked for on every large launch rather than remembered
+        PVX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sort_gather_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kSortMaxKeys * (int)sizeof(unsigned long long)));
+    hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(segments), dim3(kSortBlock), lds, st, boxes, box_stride, scores, counts, n_cap, P,
+                       score_thresh, pre_max, sorted, order, eff);
+    PVX_CHECK_LAUNCH();
+    dim3 grid(cb_cap, cb_cap, segments);
+    if (normal)
+        hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, sorted, eff, n_cap, n_cap, cb_cap, nms_thresh, mask);
+    else
+        hipLaunchKernelGGL(nms_mask_kernel<0>, grid, dim3(kBlock), 0, st, sorted, eff, n_cap, n_cap, cb_cap, nms_thresh, mask);
+    PVX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(segments), dim3(kBlock), 0, st, mask, eff, n_cap, n_cap, cb_cap, keep, num_selected,
+                       (const int*)order, (long long*)selected, post_max);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

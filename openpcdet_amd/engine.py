@@ -17,6 +17,7 @@ The arithmetic is the module path's: the same kernels, the same rulebooks; tests
 against the other.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -328,7 +329,7 @@ class HotPathEngine:
                 self.voxelize(stream.cuda_stream)
                 self._vox_done.record(stream)
 
-    def forward(self, overlap=True, pipelined=False, prevoxelized=False, mark_after=None):
+    def forward(self, overlap=True, pipelined=False, prevoxelized=False, mark_after=None, mark2_after=None):
         """voxelize the loaded frames and run the backbone; returns the dense BEV tensor [B, C*D, H, W] (a view of a
         static buffer) or None.  No host synchronisation.
 
@@ -365,6 +366,8 @@ class HotPathEngine:
                 n_conv = 0
                 if mark_after is not None and getattr(self, "mark", None) is None:
                     self.mark = torch.cuda.Event()
+                if mark2_after and getattr(self, "mark2", None) is None:
+                    self.mark2 = torch.cuda.Event()      # a second marker for another consumer (the NMS stream)
                 for name, fn in self.ops:
                     if name in self._GEOMETRY:
                         fn(g)
@@ -376,10 +379,12 @@ class HotPathEngine:
                             main.wait_event(pending)
                             pending = None
                         fn(m)
-                        if mark_after is not None and name.startswith("conv"):
+                        if (mark_after is not None or mark2_after) and name.startswith("conv"):
                             n_conv += 1
                             if n_conv == mark_after:
                                 self.mark.record(main)    # the mark_after-th conv launch of this forward has been enqueued
+                            if n_conv == mark2_after:
+                                self.mark2.record(main)
                 if pending is not None:
                     main.wait_event(pending)
                 self._done.record(main)
@@ -449,18 +454,30 @@ class BatchedNMS:
         dev = torch.device(device)
         self.device = dev
         L = _lib.lib()
-        self.sorted_boxes = torch.zeros((self.S, self.cap, 7), dtype=torch.float32, device=dev)
-        self.keep = torch.zeros((self.S, self.cap), dtype=torch.int64, device=dev)
+        from .ops.iou3d_nms import iou3d_nms_utils
+        self._select = iou3d_nms_utils.nms_select
+        # problems too large for the in-LDS sort (and PVX_NMS_TORCH_FRONT=1, a diagnostic) sort and gather with torch
+        self.fused = self.cap <= iou3d_nms_utils.NMS_SELECT_MAX and not os.environ.get("PVX_NMS_TORCH_FRONT")
         self.num = torch.zeros(self.S, dtype=torch.int32, device=dev)
-        self.ws = _lib.workspace(L.pvx_nms_workspace_bytes(self.cap, self.S), dev)
-        self._idx = torch.arange(self.cap, device=dev).unsqueeze(0)
+        if self.fused:
+            self.sel = torch.zeros((self.S, self.post_max), dtype=torch.int64, device=dev)
+            self.ws = _lib.workspace(L.pvx_nms_select_workspace_bytes(self.cap, self.S), dev)
+        else:
+            self.sorted_boxes = torch.zeros((self.S, self.cap, 7), dtype=torch.float32, device=dev)
+            self.keep = torch.zeros((self.S, self.cap), dtype=torch.int64, device=dev)
+            self.ws = _lib.workspace(L.pvx_nms_workspace_bytes(self.cap, self.S), dev)
+            self._idx = torch.arange(self.cap, device=dev).unsqueeze(0)
 
     def __call__(self, boxes, scores, counts):
         """boxes [S, cap, >=7], scores [S, cap], counts [S] int32 -> (sel [S, post_max] int64 indices into each
-        segment's boxes in descending score order, num [S] int32 = min(kept, post_max)); no host sync."""
+        segment's boxes in descending score order, num [S] int32 = min(kept, post_max)); no host sync.  Sort, gather,
+        NMS and the selection run in pvx_nms_select_batched's three launches into buffers owned here."""
+        if self.fused:
+            return self._select(boxes, scores, counts, self.thresh, self.normal, post_max=self.post_max,
+                                out=(self.sel, self.num), ws=self.ws)
         S, cap = self.S, self.cap
         masked = scores.masked_fill(self._idx >= counts.view(-1, 1), float('-inf'))   # scalar as a kernel argument: no H2D copy
-        order = masked.sort(1, descending=True)[1]
+        order = masked.sort(dim=1, descending=True, stable=True)[1]
         torch.gather(boxes[..., :7], 1, order.unsqueeze(-1).expand(S, cap, 7), out=self.sorted_boxes)
         L = _lib.lib()
         with torch.cuda.device(self.device):

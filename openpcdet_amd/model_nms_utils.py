@@ -29,10 +29,22 @@ def _topk_nms(scores, boxes, cfg):
     return top[keep[:cfg.NMS_POST_MAXSIZE]]
 
 
+_FUSED = {"nms_gpu": 0, "nms_normal_gpu": 1}
+
+
 def class_agnostic_nms(box_scores, box_preds, nms_config, score_thresh=None):
     """-> (selected indices into the ORIGINAL box list, their scores)   (model_nms_utils.py:6-25)"""
     cfg = _cfg(nms_config)
     all_scores = box_scores
+    n = box_scores.shape[0]
+    if (box_scores.is_cuda and 0 < n <= iou3d_nms_utils.NMS_SELECT_MAX and cfg.NMS_TYPE in _FUSED
+            and box_scores.dtype == torch.float32 and box_preds.dtype == torch.float32):
+        # the whole function in three launches on the device; one host read (the kept count) shapes the result
+        sel, num = iou3d_nms_utils.nms_select(box_preds.unsqueeze(0), box_scores.unsqueeze(0), None, cfg.NMS_THRESH,
+                                              normal=_FUSED[cfg.NMS_TYPE], score_thresh=score_thresh,
+                                              pre_max=cfg.NMS_PRE_MAXSIZE, post_max=min(cfg.NMS_POST_MAXSIZE, n))
+        selected = sel[0, :int(num.item())]
+        return selected, all_scores[selected]
     if score_thresh is not None:
         passed = box_scores >= score_thresh
         box_scores, box_preds = box_scores[passed], box_preds[passed]

@@ -116,6 +116,44 @@ def nms_normal_gpu(boxes, scores, thresh, **kwargs):
     return order[keep[:int(num.item())]].contiguous(), None
 
 
+NMS_SELECT_MAX = 16384      # pvx_nms_select_batched: one problem's sort keys live in one CU's LDS
+
+
+def nms_select(boxes, scores, counts, thresh, normal=False, score_thresh=None, pre_max=None, post_max=None, out=None, ws=None):
+    """class_agnostic_nms (model_nms_utils.py:6-25) for S problems at once, all of it on the device in three launches
+    (pvx_nms_select_batched): score threshold, top-pre_max by score (ties: lower index first), NMS, keep[:post_max] mapped
+    back to the caller's indices.
+
+    boxes (S, cap, >=7) float32, scores (S, cap) float32, counts (S,) int32 or None; cap <= NMS_SELECT_MAX.
+    -> (sel (S, post_max) int64, num (S,) int32): sel[s, :num[s]] index segment s's boxes, best score first; entries
+    beyond num[s] repeat the best-scored index.  No host sync.  `out` = (sel, num) and `ws` reuse caller buffers."""
+    S, cap = scores.shape
+    dev = boxes.device
+    assert boxes.dim() == 3 and boxes.shape[:2] == (S, cap) and boxes.shape[2] >= 7
+    assert boxes.dtype == torch.float32 and scores.dtype == torch.float32 and cap <= NMS_SELECT_MAX
+    boxes, scores = boxes.contiguous(), scores.contiguous()
+    post = cap if post_max is None else int(post_max)
+    if out is None:
+        sel = torch.zeros((S, post), dtype=torch.int64, device=dev)
+        num = torch.zeros(S, dtype=torch.int32, device=dev)
+    else:
+        sel, num = out
+        assert sel.shape == (S, post) and sel.dtype == torch.int64 and sel.is_contiguous() and num.dtype == torch.int32
+    if S > 0 and cap > 0 and post > 0:
+        if counts is not None:
+            counts = counts.to(torch.int32).contiguous()
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            if ws is None:
+                ws = _lib.workspace(L.pvx_nms_select_workspace_bytes(cap, S), dev)
+            _lib.check(L.pvx_nms_select_batched(_lib.ptr(boxes), boxes.shape[2], _lib.ptr(scores), _lib.ptr(counts), S, cap,
+                                                float('-inf') if score_thresh is None else float(score_thresh),
+                                                0 if pre_max is None else int(pre_max), float(thresh), int(normal), post,
+                                                _lib.ptr(sel), _lib.ptr(num), _lib.ptr(ws), ws.numel(), _lib.stream()),
+                       "pvx_nms_select_batched")
+    return sel, num
+
+
 def nms_batched(boxes, scores, counts, thresh, normal=False):
     """Many independent NMS problems in one launch (CenterHead runs 6 heads x B frames,
     center_head.py:332-384).
@@ -126,6 +164,9 @@ def nms_batched(boxes, scores, counts, thresh, normal=False):
     """
     S, cap = scores.shape
     dev = boxes.device
+    if cap <= NMS_SELECT_MAX:
+        return nms_select(boxes.float(), scores.float(), counts, thresh, normal)
+    # larger problems: sort with torch, NMS over the sorted boxes
     idx = torch.arange(cap, device=dev).unsqueeze(0)
     masked = torch.where(idx < counts.view(-1, 1).long(), scores, torch.full_like(scores, float('-inf')))
     order = masked.sort(1, descending=True)[1]

@@ -155,3 +155,70 @@ def test_nms_idempotent_full_size(cuda_device):
     iou = U.boxes_iou_bev(kept[:2000], kept[:2000])
     iou = torch.triu(iou, diagonal=1)
     assert float(iou.max()) <= 0.8
+
+
+def _select_oracle(boxes, scores, count, thresh, normal, score_thresh, pre_max, post_max):
+    """model_nms_utils.py:6-25 in numpy over the oracle NMS: indices into the segment's own boxes"""
+    idx = np.arange(count)
+    sc = scores[:count]
+    if score_thresh is not None:
+        idx = idx[sc >= score_thresh]
+    order = idx[np.argsort(-scores[idx], kind="stable")]          # descending score, ties by ascending index
+    if pre_max is not None:
+        order = order[:pre_max]
+    keep, margin = loader.nms(boxes[order][:, :7], thresh, normal=normal)
+    return order[keep[:post_max]], margin
+
+
+@pytest.mark.parametrize("cap,S", [(500, 7), (64, 3), (5000, 2), (16384, 1)])
+def test_nms_select_vs_oracle(cuda_device, cap, S):
+    """pvx_nms_select_batched (threshold + top-k sort + gather + NMS + post-max mapping on the device) vs the numpy
+    restatement of class_agnostic_nms over the oracle NMS: bit-exact index lists.  Ragged counts with an empty segment,
+    tied scores (ties resolve to the lower index), 9-wide boxes, LDS sort sizes below and above the 32 KiB opt-in."""
+    rng = np.random.default_rng(100 + cap)
+    boxes = np.zeros((S, cap, 9), np.float32)
+    scores = np.zeros((S, cap), np.float32)
+    counts = np.array(([cap, 0, cap - 1, 1, 65, cap // 2, 17] * 3)[:S], np.int32)
+    for s in range(S):
+        boxes[s, :, :7] = _rand_boxes(rng, cap, 0.35 * np.sqrt(cap) + s)
+        boxes[s, :, 7:] = rng.normal(size=(cap, 2))
+        scores[s] = (rng.integers(0, max(cap // 3, 2), cap) / max(cap // 3, 2)).astype(np.float32)    # many ties
+    tb, ts, tc = (torch.from_numpy(x).to(cuda_device) for x in (boxes, scores, counts))
+    cases = ((False, None, None, None), (False, 0.3, cap // 2 + 1, 83), (True, 0.1, None, 40), (False, 2.0, None, 10))
+    if cap > 6000:
+        cases = cases[1:2]                              # the CPU checker is O(n^2): one configuration at the largest size
+    for normal, score_thresh, pre_max, post_max in cases:
+        sel, num = U.nms_select(tb, ts, tc, 0.2, normal=normal, score_thresh=score_thresh, pre_max=pre_max, post_max=post_max)
+        post = cap if post_max is None else post_max
+        assert sel.shape == (S, post) and sel.dtype == torch.int64 and num.dtype == torch.int32
+        sel, num = sel.cpu().numpy(), num.cpu().numpy()
+        for s in range(S):
+            want, margin = _select_oracle(boxes[s], scores[s], counts[s], 0.2, normal, score_thresh, pre_max, post)
+            assert num[s] == want.size, (s, normal, score_thresh, margin)
+            assert np.array_equal(sel[s, :num[s]], want), (s, normal, score_thresh, margin)
+            if num[s] < post and want.size:
+                assert np.all(sel[s, num[s]:] == want[0])
+    # no counts array = every box valid; second call on the same buffers with other data (nothing stale is read)
+    sel, num = U.nms_select(tb[:, :, :7].contiguous(), ts, None, 0.2, post_max=50)
+    for s in range(S):
+        want, _ = _select_oracle(boxes[s], scores[s], cap, 0.2, False, None, None, 50)
+        assert np.array_equal(sel[s, :int(num[s])].cpu().numpy(), want)
+
+
+def test_nms_select_limits(cuda_device):
+    from openpcdet_amd import _lib
+    L = _lib.lib()
+    b = torch.zeros((1, 16385, 7), device=cuda_device)
+    s = torch.zeros((1, 16385), device=cuda_device)
+    sel = torch.zeros((1, 10), dtype=torch.int64, device=cuda_device)
+    num = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    ws = torch.zeros(1 << 20, dtype=torch.uint8, device=cuda_device)
+    rc = L.pvx_nms_select_batched(_lib.ptr(b), 7, _lib.ptr(s), None, 1, 16385, float("-inf"), 0, 0.5, 0, 10, _lib.ptr(sel), _lib.ptr(num),
+                                  _lib.ptr(ws), ws.numel(), None)
+    assert rc == -4                                   # PVX_ERR_RANGE: more keys than one CU's LDS sorts
+    rc = L.pvx_nms_select_batched(_lib.ptr(b), 7, _lib.ptr(s), None, 1, 4096, float("-inf"), 0, 0.5, 0, 10, _lib.ptr(sel), _lib.ptr(num),
+                                  _lib.ptr(ws), ws.numel(), None)
+    assert rc == -2                                   # PVX_ERR_WORKSPACE: the mask alone needs 2 MiB
+    rc = L.pvx_nms_select_batched(_lib.ptr(b), 6, _lib.ptr(s), None, 1, 64, float("-inf"), 0, 0.5, 0, 10, _lib.ptr(sel), _lib.ptr(num),
+                                  _lib.ptr(ws), ws.numel(), None)
+    assert rc == -1                                   # PVX_ERR_INVALID: rows narrower than a box
