@@ -54,7 +54,8 @@ def build_model(cfg, dev):
 
 
 def make_inputs(cfg, rank, pool, dev):
-    frames = [torch.from_numpy(synth.config_cloud(WORKLOAD, 1000 * rank + 3 + i)).to(dev) for i in range(pool)]
+    # one contiguous pool [pool, n_points, C]: a step's B frames are one slice of it (two when the ring wraps)
+    frames = torch.from_numpy(np.stack([synth.config_cloud(WORKLOAD, 1000 * rank + 3 + i) for i in range(pool)])).to(dev)
     S = HEADS
     boxes = np.zeros((pool, S, BOXES_PER_HEAD, 9), np.float32)
     scores = np.zeros((pool, S, BOXES_PER_HEAD), np.float32)
@@ -163,17 +164,23 @@ def main():
     s_scores = torch.zeros((B * HEADS, BOXES_PER_HEAD), device=dev)
     s_counts = torch.zeros((B * HEADS,), dtype=torch.int32, device=dev)
 
+    def ring(step):
+        """the step's frames (step * B + b) % P, b < B, as (destination offset, pool offset, length) runs"""
+        start = (step * B) % P
+        first = min(B, P - start)
+        return [(0, start, first)] + ([(first, 0, B - first)] if first < B else [])
+
     def load_points(step, plan=None):
+        # the new batch arrives in the plan's input buffer: one device copy per run instead of one per frame
         plan = eng if plan is None else plan
-        for b in range(B):
-            plan.points[b].copy_(frames[(step * B + b) % P])
+        for dst, src, k in ring(step):
+            plan.points[dst:dst + k].copy_(frames[src:src + k])
 
     def load_boxes(step):
-        for b in range(B):
-            i = (step * B + b) % P
-            s_boxes[b * HEADS:(b + 1) * HEADS].copy_(boxes[i])
-            s_scores[b * HEADS:(b + 1) * HEADS].copy_(scores[i])
-            s_counts[b * HEADS:(b + 1) * HEADS].copy_(counts[i])
+        for dst, src, k in ring(step):
+            s_boxes[dst * HEADS:(dst + k) * HEADS].copy_(boxes[src:src + k].flatten(0, 1))
+            s_scores[dst * HEADS:(dst + k) * HEADS].copy_(scores[src:src + k].flatten(0, 1))
+            s_counts[dst * HEADS:(dst + k) * HEADS].copy_(counts[src:src + k].flatten(0, 1))
 
     def load(step):
         load_points(step)
