@@ -137,6 +137,16 @@ int pvx_voxelize_hard(const float* points, int n, int c, const float* vsize_xyz,
                       int* num_points_per_voxel, float* mean, int* point_to_voxel, int* num_voxels,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* pvx_voxelize_hard for `frames` clouds of n points each in one set of launches (points [frames, n, c]); every output gains
+ * a leading [frames] dimension (voxels [frames, max_voxels, T, c], coords_zyx [frames, max_voxels, 3], num_points_per_voxel
+ * [frames, max_voxels], point_to_voxel [frames, n], num_voxels [frames]).  Clouds shorter than n are padded with NaN rows
+ * (never in range).  This is the test-time DOUBLE_FLIP path of transform_points_to_voxels (data_processor.py:225-242):
+ * the cloud and its y-, x- and xy-flipped copies voxelized together.  Workspace: pvx_voxelize_batch_workspace_bytes. */
+int pvx_voxelize_hard_batch(const float* points, int frames, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                            int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
+                            int* num_points_per_voxel, int* point_to_voxel, int* num_voxels, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Frame `batch_idx` of a batch, voxelized straight into the backbone's input rows with no host round trip: the same
  * first-come voxelization as pvx_voxelize_hard, but the M voxels are APPENDED at rows [base, base + M) of the
  * batch-level arrays, base = *row_base_dev (NULL = 0), fusing MeanVFE.forward, the batch-index column that

@@ -41,6 +41,8 @@ SIGNATURES = {
     "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "pvx_voxel_grid_size": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pvx_voxelize_hard_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "pvx_voxelize_hard_batch": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_voxelize_hard": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_voxelize_mean_append": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,

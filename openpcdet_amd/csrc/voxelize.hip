@@ -444,6 +444,18 @@ extern "C" int pvx_voxelize_hard(const float* points, int n, int c, const float*
     return voxelize_impl(points, 1, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes, stream);
 }
 
+extern "C" int pvx_voxelize_hard_batch(const float* points, int frames, int n, int c, const float* vsize_xyz, const float* range_xyz,
+                                       int max_points_per_voxel, int max_voxels, float* voxels, int* coords_zyx,
+                                       int* num_points_per_voxel, int* point_to_voxel, int* num_voxels, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!coords_zyx) return PVX_ERR_INVALID;
+    // batch = false: every frame keeps its own [max_voxels] output block and its own voxel ids (no shared row space)
+    VoxOut o = { voxels, coords_zyx, num_points_per_voxel, nullptr, c, PVX_F32, point_to_voxel, num_voxels, nullptr, 0, nullptr,
+                 max_voxels, nullptr, false };
+    return voxelize_impl(points, frames, n, c, vsize_xyz, range_xyz, max_points_per_voxel, max_voxels, o, workspace, workspace_bytes,
+                         stream);
+}
+
 extern "C" int pvx_voxelize_mean_append(const float* points, int n, int c, const float* vsize_xyz, const float* range_xyz,
                                         int max_points_per_voxel, int max_voxels, int batch_idx, const int* row_base_dev,
                                         int row_capacity, int* coords_bzyx, void* mean, int mean_stride, int mean_dtype,

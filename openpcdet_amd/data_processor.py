@@ -70,15 +70,37 @@ class DataProcessorGPU:
     def transform_points_to_voxels_placeholder(self, data_dict, config):
         return data_dict
 
+    # data_processor.py:124-138
+    @staticmethod
+    def double_flip(points):
+        """-> (y-flipped, x-flipped, xy-flipped) copies of a [N, C] device tensor"""
+        y, x, xy = points.clone(), points.clone(), points.clone()
+        y[:, 1] = -y[:, 1]
+        x[:, 0] = -x[:, 0]
+        xy[:, 0] = -xy[:, 0]
+        xy[:, 1] = -xy[:, 1]
+        return y, x, xy
+
     # data_processor.py:200-247
     def transform_points_to_voxels(self, data_dict, config):
         if self.voxel_generator is None:
             self.voxel_generator = voxelize.PointToVoxel(self.voxel_size, self.point_cloud_range.tolist(), self.num_point_features,
                                                          int(_get(config, 'MAX_NUMBER_OF_VOXELS')[self.mode]),
                                                          int(_get(config, 'MAX_POINTS_PER_VOXEL')))
-        out = self.voxel_generator.run(data_dict['points'])
+        points = data_dict['points']
+        lead = 0 if data_dict.get('use_lead_xyz', True) else 3       # :222-223 drops xyz from the voxel rows
+        if _get(config, 'DOUBLE_FLIP', False):
+            # the cloud and its three flipped copies (:225-242) are four frames of ONE batched voxelization; the lists keep the
+            # reference's order [original, yflip, xflip, xyflip]
+            out = self.voxel_generator.run_batch(torch.stack((points,) + self.double_flip(points)))
+            counts = out['num_voxels'].tolist()                      # one host read for the four sizes
+            data_dict['voxels'] = [out['voxels'][f, :n, :, lead:] for f, n in enumerate(counts)]
+            data_dict['voxel_coords'] = [out['coords'][f, :n] for f, n in enumerate(counts)]
+            data_dict['voxel_num_points'] = [out['num_points'][f, :n] for f, n in enumerate(counts)]
+            return data_dict
+        out = self.voxel_generator.run(points)
         n = int(out['num_voxels'].item())              # the reference hands on exactly-sized arrays
-        data_dict['voxels'] = out['voxels'][:n]
+        data_dict['voxels'] = out['voxels'][:n, :, lead:]
         data_dict['voxel_coords'] = out['coords'][:n]
         data_dict['voxel_num_points'] = out['num_points'][:n]
         return data_dict

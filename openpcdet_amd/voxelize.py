@@ -63,6 +63,32 @@ class PointToVoxel:
                                            ws.numel(), _lib.stream()), "pvx_voxelize_hard")
         return out
 
+    def run_batch(self, clouds, want_point_map=False):
+        """clouds [F, N, C] float32 on the GPU (shorter clouds padded with NaN rows) -> dict of [F, ...] padded-capacity
+        tensors + 'num_voxels' (device int32[F]): F independent voxelizations in one set of launches
+        (pvx_voxelize_hard_batch; the DOUBLE_FLIP path of data_processor.py:225-242).  No host synchronisation."""
+        assert clouds.is_cuda and clouds.dtype == torch.float32 and clouds.dim() == 3
+        assert clouds.shape[2] == self.num_point_features
+        clouds = clouds.contiguous()
+        F, n, c = clouds.shape
+        dev = clouds.device
+        M, T = self.max_num_voxels, self.max_num_points_per_voxel
+        L = _lib.lib()
+        out = {
+            "coords": torch.empty((F, M, 3), dtype=torch.int32, device=dev),
+            "num_points": torch.empty((F, M), dtype=torch.int32, device=dev),
+            "num_voxels": torch.zeros((F,), dtype=torch.int32, device=dev),
+            "voxels": torch.empty((F, M, T, c), dtype=torch.float32, device=dev),
+            "point_to_voxel": torch.empty((F, n), dtype=torch.int32, device=dev) if want_point_map else None,
+        }
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(L.pvx_voxelize_batch_workspace_bytes(F, n, M, T), dev)
+            _lib.check(L.pvx_voxelize_hard_batch(_lib.ptr(clouds), F, n, c, self._v, self._r, T, M, _lib.ptr(out["voxels"]),
+                                                 _lib.ptr(out["coords"]), _lib.ptr(out["num_points"]),
+                                                 _lib.ptr(out["point_to_voxel"]), _lib.ptr(out["num_voxels"]), _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream()), "pvx_voxelize_hard_batch")
+        return out
+
     def __call__(self, points):
         """spconv-style result: (voxels [M,T,C], indices [M,3] zyx, num_per_voxel [M]) sliced to the true M
         (one host read of M, like the reference's `[:voxel_num]` views)."""

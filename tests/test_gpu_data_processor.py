@@ -51,3 +51,55 @@ def test_train_pipeline_shuffles_and_filters_boxes(cuda_device):
     assert np.array_equal(out['voxel_coords'].cpu().numpy(), coords) and np.array_equal(out['voxels'].cpu().numpy(), vox)
     with pytest.raises(NotImplementedError):
         data_processor.DataProcessorGPU([dict(NAME='image_normalize')], RANGE, False, 4)
+
+
+def test_double_flip_and_no_lead_xyz(cuda_device):
+    """test-time DOUBLE_FLIP (data_processor.py:225-242): lists [original, yflip, xflip, xyflip], each equal to the voxelizer oracle
+    on the numpy-flipped cloud; use_lead_xyz = False drops the xyz columns (:222-223, 234-235).  The cap of 3000 voxels bites."""
+    rng = [-30.0, -20.0, -3.0, 30.0, 20.0, 1.0]
+    cfg = [dict(NAME='mask_points_and_boxes_outside_range', REMOVE_OUTSIDE_BOXES=False),
+           dict(NAME='transform_points_to_voxels', VOXEL_SIZE=[0.2, 0.2, 0.4], MAX_POINTS_PER_VOXEL=4, DOUBLE_FLIP=True,
+                MAX_NUMBER_OF_VOXELS={'train': 3000, 'test': 3000})]
+    r = np.random.default_rng(4)
+    pts = np.concatenate([r.uniform(-33, 33, (20000, 1)), r.uniform(-22, 22, (20000, 1)), r.uniform(-4, 2, (20000, 1)),
+                          r.uniform(0, 1, (20000, 2))], 1).astype(np.float32)
+    for lead in (True, False):
+        dp = data_processor.DataProcessorGPU(cfg, rng, training=False, num_point_features=5, device=cuda_device)
+        out = dp.forward({'points': pts.copy(), 'use_lead_xyz': lead})
+        kept = out['points'].cpu().numpy()
+        assert isinstance(out['voxels'], list) and len(out['voxels']) == len(out['voxel_coords']) == len(out['voxel_num_points']) == 4
+        for k, (sx, sy) in enumerate(((1, 1), (1, -1), (-1, 1), (-1, -1))):
+            flipped = kept.copy()
+            flipped[:, 0] *= sx
+            flipped[:, 1] *= sy
+            vox, coords, num = loader.voxelize_hard(flipped, [0.2, 0.2, 0.4], rng, 4, 3000)[:3]
+            assert len(coords) == 3000
+            assert np.array_equal(out['voxel_coords'][k].cpu().numpy(), coords), k
+            assert np.array_equal(out['voxel_num_points'][k].cpu().numpy(), num), k
+            assert np.array_equal(out['voxels'][k].cpu().numpy(), vox if lead else vox[..., 3:]), k
+    # single-cloud path honours use_lead_xyz too
+    cfg[1]['DOUBLE_FLIP'] = False
+    dp = data_processor.DataProcessorGPU(cfg, rng, training=False, num_point_features=5, device=cuda_device)
+    out = dp.forward({'points': pts.copy(), 'use_lead_xyz': False})
+    vox = loader.voxelize_hard(out['points'].cpu().numpy(), [0.2, 0.2, 0.4], rng, 4, 3000)[0]
+    assert np.array_equal(out['voxels'].cpu().numpy(), vox[..., 3:])
+
+
+def test_run_batch_ragged_clouds(cuda_device):
+    """pvx_voxelize_hard_batch: clouds of different lengths padded with NaN rows, each frame equal to its own oracle run"""
+    from openpcdet_amd import voxelize
+    gen = voxelize.PointToVoxel([0.1, 0.1, 0.2], RANGE, 4, 40000, 5)
+    sizes = (30000, 1, 17000, 0)
+    clouds = np.full((len(sizes), max(sizes), 4), np.nan, np.float32)
+    for f, n in enumerate(sizes):
+        clouds[f, :n] = cloud(10 + f, n) if n else 0
+    out = gen.run_batch(torch.from_numpy(clouds).to(cuda_device), want_point_map=True)
+    counts = out['num_voxels'].tolist()
+    for f, n in enumerate(sizes):
+        vox, coords, num, p2v = loader.voxelize_hard(clouds[f, :n], [0.1, 0.1, 0.2], RANGE, 5, 40000)
+        assert counts[f] == len(coords)
+        assert np.array_equal(out['coords'][f, :counts[f]].cpu().numpy(), coords)
+        assert np.array_equal(out['num_points'][f, :counts[f]].cpu().numpy(), num)
+        assert np.array_equal(out['voxels'][f, :counts[f]].cpu().numpy(), vox)
+        assert np.array_equal(out['point_to_voxel'][f, :n].cpu().numpy(), p2v)
+        assert (out['point_to_voxel'][f, n:] == -1).all()
