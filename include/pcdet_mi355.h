@@ -395,6 +395,43 @@ int pvx_voxel_query(const float* new_xyz, const int* new_coords, int m, const fl
                     int batch, int z, int y, int x, const int* max_range_zyx, float radius, int nsample, int* idx,
                     unsigned char* empty_mask, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * VectorPool aggregation (PV-RCNN++ second stage).  Stacked layout as in the reference:
+ * support_xyz [N, 3] / support_features [N, C] hold the frames one after another, xyz_batch_cnt [batch] (device int32) their
+ * lengths; new_xyz [M, 3] and new_xyz_batch_cnt likewise.  neighbor_type 1 = ball, else cube; nsample <= 0 = no limit.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* For every new point the first min(nsample, 1000) support points of its frame within max_neighbour_distance (index order), then
+ * for each of its num_total_grids grid centres [M, G, 3] the three nearest of those: dist2 [M, G, 3] (squared; +inf when the
+ * list is empty), idx [M, G, 3] (row in support_xyz; -1 when empty; the nearest repeated when fewer than three).
+ * *total_neighbors (device) = summed list lengths.  Replaces query_stacked_local_neighbor_idxs_kernel +
+ * query_three_nn_by_stacked_local_idxs_kernel (vector_pool_gpu.cu:122-205, 19-86) and the guess-and-retry loop around them
+ * (pointnet2_utils.py:331-353): the list stays in LDS, nothing is stacked in HBM. */
+int pvx_vector_pool_three_nn(const float* support_xyz, int n_support, const int* xyz_batch_cnt, const float* new_xyz,
+                             const float* new_xyz_grid_centers, const int* new_xyz_batch_cnt, int batch_size, int m,
+                             int num_total_grids, float max_neighbour_distance, int nsample, int neighbor_type,
+                             float* dist2, int* idx, int* total_neighbors, void* stream);
+
+/* vector_pool_kernel_stack (vector_pool_gpu.cu:243-373): per new point and local grid cell (gx * gy * gz cells over the cube of
+ * half-width max_neighbour_distance) the SUM (pooling_type 0) or the FIRST (1) of the support features / local offsets that
+ * fall into it; new_features [M, G * c_each] (input channel i lands in i % c_each), new_local_xyz [M, G * 3],
+ * point_cnt_of_grid [M, G], grouped_idxs [num_max_sum_points, 3] = (support row, new point, cell) of every pooled point for
+ * the backward pass, *cum_sum (device) = how many there are (entries beyond the buffer are dropped: call again with
+ * num_max_sum_points >= *cum_sum; unlike the reference the count does not depend on the buffer size).  Outputs are zeroed
+ * by the call; division by the counts is the caller's (pointnet2_utils.py:419-423).  G <= 2048. */
+int pvx_vector_pool(const float* support_xyz, const float* support_features, int n_support, const int* xyz_batch_cnt,
+                    const float* new_xyz, const int* new_xyz_batch_cnt, int batch_size, int m, int num_c_in,
+                    int num_c_each_grid, int num_grid_x, int num_grid_y, int num_grid_z, float max_neighbour_distance,
+                    int use_xyz, int nsample, int neighbor_type, int pooling_type, float* new_features,
+                    float* new_local_xyz, int* point_cnt_of_grid, int* grouped_idxs, int num_max_sum_points,
+                    int* cum_sum, void* stream);
+
+/* vector_pool_grad_kernel_stack (vector_pool_gpu.cu:433-458): grad_support_features [N, C] (zeroed by the call) +=
+ * grad_new_features[new point, cell * c_each + channel % c_each] / max(count, 1) for every grouped entry. */
+int pvx_vector_pool_grad(const float* grad_new_features, const int* point_cnt_of_grid, const int* grouped_idxs,
+                         long long num_entries, int m, int n_support, int num_c_in, int num_c_each_grid,
+                         int num_total_grids, float* grad_support_features, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,13 @@ SIGNATURES = {
     "pvx_nms_select_workspace_bytes": (c_size_t, [c_int, c_int]),
     "pvx_nms_select_batched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_float, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_vector_pool_three_nn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pvx_vector_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p]),
+    "pvx_vector_pool_grad": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
     "pvx_nms_static": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev_cpu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

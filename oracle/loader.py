@@ -217,3 +217,45 @@ def dense(feat, coords, batch, shape):
     out = np.zeros((batch, ch, shape[0], shape[1], shape[2]), np.float32)
     oracle().orc_dense(fptr(f), c.ctypes.data_as(_ip), n, ch, batch, _i3(shape), fptr(out))
     return out
+
+
+# ---- VectorPool (vector_pool_oracle.c) -------------------------------------------------------------------------------------
+def vp_three_nn(support_xyz, xyz_cnt, new_xyz, centers, new_cnt, max_dist, nsample, neighbor_type):
+    """-> dist2 [M, G, 3] f32, idx [M, G, 3] i32, summed neighbour-list lengths"""
+    s, q, c = f32(support_xyz), f32(new_xyz), f32(centers)
+    xc, nc = _i32(xyz_cnt), _i32(new_cnt)
+    M, G = c.shape[0], c.shape[1]
+    d2 = np.zeros((M, G, 3), np.float32)
+    idx = np.zeros((M, G, 3), np.int32)
+    fn = oracle().orc_vp_three_nn
+    fn.restype = ctypes.c_longlong
+    total = fn(fptr(s), xc.ctypes.data_as(_ip), fptr(q), fptr(c), nc.ctypes.data_as(_ip), len(xc), M, G, ctypes.c_float(max_dist),
+               int(nsample), int(neighbor_type), fptr(d2), idx.ctypes.data_as(_ip))
+    return d2, idx, int(total)
+
+
+def vector_pool(support_xyz, support_feat, xyz_cnt, new_xyz, new_cnt, ceach, grids, max_dist, use_xyz, nsample, neighbor_type, pooling, cap):
+    """raw sums (not yet divided by the counts) -> new_features [M, G*ceach], new_local_xyz [M, G*3], cnt [M, G], grouped [min(cum, cap), 3], cum"""
+    s, f, q = f32(support_xyz), f32(support_feat), f32(new_xyz)
+    xc, nc = _i32(xyz_cnt), _i32(new_cnt)
+    M, cin = q.shape[0], f.shape[1]
+    G = grids[0] * grids[1] * grids[2]
+    nf = np.zeros((M, G * ceach), np.float32)
+    nl = np.zeros((M, G * 3), np.float32)
+    cnt = np.zeros((M, G), np.int32)
+    grouped = np.zeros((max(cap, 1), 3), np.int32)
+    fn = oracle().orc_vector_pool
+    fn.restype = ctypes.c_longlong
+    cum = int(fn(fptr(s), fptr(f), xc.ctypes.data_as(_ip), fptr(q), nc.ctypes.data_as(_ip), len(xc), M, cin, int(ceach), int(grids[0]),
+                 int(grids[1]), int(grids[2]), ctypes.c_float(max_dist), int(use_xyz), int(nsample), int(neighbor_type), int(pooling),
+                 fptr(nf), fptr(nl), cnt.ctypes.data_as(_ip), grouped.ctypes.data_as(_ip), ctypes.c_longlong(cap)))
+    return nf, nl, cnt, grouped[:min(cum, cap)].copy(), cum
+
+
+def vector_pool_grad(grad_new, cnt, grouped, n_support, cin, ceach):
+    g = f32(grad_new)
+    c, gr = _i32(cnt), _i32(grouped)
+    out = np.zeros((n_support, cin), np.float32)
+    oracle().orc_vector_pool_grad(fptr(g), c.ctypes.data_as(_ip), gr.ctypes.data_as(_ip), ctypes.c_longlong(len(gr)), int(cin), int(ceach),
+                                  int(c.shape[1]), fptr(out))
+    return out
