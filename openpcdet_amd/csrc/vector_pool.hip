@@ -20,6 +20,8 @@ namespace {
 
 constexpr int kWaves = 4;                 // new points per workgroup
 constexpr int kBlk = kWaves * 64;
+constexpr int kUnroll = 4;               // 64-point steps whose loads are issued together
+constexpr int kRecBuf = 256;              // pooled-point records a wave collects in LDS per reservation in grouped_idxs
 constexpr int kListCap = 1000;            // temp_idxs[1000], vector_pool_gpu.cu:162,184-189
 
 struct Frame { int start, n; };
@@ -63,20 +65,26 @@ __global__ __launch_bounds__(kBlk) void vp_three_nn_kernel(const float* __restri
     const float* s = sxyz + (size_t)fr.start * 3;
     const float nx = nxyz[pt * 3], ny = nxyz[pt * 3 + 1], nz = nxyz[pt * 3 + 2];
     int count = 0;
-    for (int base = 0; base < fr.n && count < cap; base += 64) {
-        const int k = base + lane;
-        bool hit = false;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (k < fr.n) {
-            x = s[(size_t)k * 3]; y = s[(size_t)k * 3 + 1]; z = s[(size_t)k * 3 + 2];
-            hit = in_range(x - nx, y - ny, z - nz, maxd, type);
+    for (int base0 = 0; base0 < fr.n && count < cap; base0 += 64 * kUnroll) {
+        float X[kUnroll], Y[kUnroll], Z[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {                // kUnroll coalesced reads in flight before the first ballot
+            const int k = base0 + u * 64 + lane;
+            X[u] = Y[u] = Z[u] = 0.f;
+            if (k < fr.n) { X[u] = s[(size_t)k * 3]; Y[u] = s[(size_t)k * 3 + 1]; Z[u] = s[(size_t)k * 3 + 2]; }
         }
-        const unsigned long long m = __ballot(hit);
-        if (hit) {
-            const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-            if (pos < cap) list[pos] = make_float4(x, y, z, __int_as_float(fr.start + k));
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+            const int k = base0 + u * 64 + lane;
+            if (count >= cap) break;                       // wave-uniform
+            const bool hit = k < fr.n && in_range(X[u] - nx, Y[u] - ny, Z[u] - nz, maxd, type);
+            const unsigned long long m = __ballot(hit);
+            if (hit) {
+                const int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < cap) list[pos] = make_float4(X[u], Y[u], Z[u], __int_as_float(fr.start + k));
+            }
+            count += __popcll(m);
         }
-        count += __popcll(m);
     }
     if (count > cap) count = cap;
     if (lane == 0) atomicAdd(total, count);
@@ -103,7 +111,23 @@ __global__ __launch_bounds__(kBlk) void vp_three_nn_kernel(const float* __restri
     }
 }
 
-// dynamic LDS per wave: G ints (points per grid cell) + 64 x int2 (the entries this 64-point step records)
+// one reservation in grouped_idxs (a single atomic on the shared counter) for the records a wave has collected, then a parallel copy
+__device__ __forceinline__ void flush_records(const int* step, int nrec, int pt, int* __restrict__ grouped, int cap, int* __restrict__ cum,
+                                              int lane) {
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(cum, nrec);
+    slot = __shfl(slot, 0);
+    for (int e = lane; e < nrec; e += 64) {
+        if ((long long)slot + e < cap) {
+            int* o = grouped + ((size_t)slot + e) * 3;
+            o[0] = step[e * 2]; o[1] = pt; o[2] = step[e * 2 + 1];
+        }
+    }
+    wave_lds_sync();                                       // step[] is rewritten afterwards
+}
+
+// dynamic LDS per wave: G ints (points per grid cell) + kRecBuf x int2 (records of pooled points awaiting their slot in grouped_idxs) and, when they fit
+// (acc_in_lds), the G x (ceach + 3) float accumulators of the new point: a hit then costs LDS round trips instead of HBM ones
 __global__ __launch_bounds__(kBlk) void vector_pool_kernel(const float* __restrict__ sxyz, const float* __restrict__ sfeat, int n_support,
                                                             const int* __restrict__ xyz_cnt, const float* __restrict__ nxyz,
                                                             const int* __restrict__ new_cnt, int batch, int M, int cin, int ceach,
@@ -111,31 +135,45 @@ __global__ __launch_bounds__(kBlk) void vector_pool_kernel(const float* __restri
                                                             int use_xyz, int nsample, int type, int pooling,
                                                             float* __restrict__ newf, float* __restrict__ newl,
                                                             int* __restrict__ cnt_of_grid, int* __restrict__ grouped, int cap,
-                                                            int* __restrict__ cum) {
+                                                            int* __restrict__ cum, int acc_in_lds) {
     extern __shared__ int lds_i[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pt = blockIdx.x * kWaves + wave;
     if (pt >= M) return;                                   // wave-uniform; no workgroup barrier below
     const int G = gx * gy * gz;
-    int* gcnt = lds_i + (size_t)wave * (G + 128);
-    int* step = gcnt + G;                                  // [64][2]: support index, grid cell
+    const int per_wave = G + 2 * kRecBuf + (acc_in_lds ? G * (ceach + 3) : 0);
+    int* gcnt = lds_i + (size_t)wave * per_wave;
+    int* step = gcnt + G;                                  // [kRecBuf][2]: support index, grid cell of the pooled points not yet written out
+    float* lacc = reinterpret_cast<float*>(step + 2 * kRecBuf);    // [G * ceach] feature sums, then [G * 3] offset sums
     for (int g = lane; g < G; g += 64) gcnt[g] = 0;
+    if (acc_in_lds)
+        for (int e = lane; e < G * (ceach + 3); e += 64) lacc[e] = 0.f;
     const Frame fr = locate(new_cnt, xyz_cnt, batch, pt, n_support);
     const float* s = sxyz + (size_t)fr.start * 3;
     const float* f = sfeat + (size_t)fr.start * cin;
     const float nx = nxyz[pt * 3], ny = nxyz[pt * 3 + 1], nz = nxyz[pt * 3 + 2];
-    float* of = newf + (size_t)pt * ceach * G;
-    float* ol = newl + (size_t)pt * 3 * G;
+    float* of = acc_in_lds ? lacc : newf + (size_t)pt * ceach * G;
+    float* ol = acc_in_lds ? lacc + G * ceach : newl + (size_t)pt * 3 * G;
     const int limit = pooling == 1 ? (nsample > 0 && nsample < G ? nsample : G) : (nsample > 0 ? nsample : 0x7fffffff);
-    int sample = 0;
+    int sample = 0, nrec = 0;
     wave_lds_sync();
-    for (int base = 0; base < fr.n && sample < limit; base += 64) {
+    for (int base0 = 0; base0 < fr.n && sample < limit; base0 += 64 * kUnroll) {
+      float X[kUnroll], Y[kUnroll], Z[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {                  // kUnroll coalesced reads in flight before the first ballot
+          const int k = base0 + u * 64 + lane;
+          X[u] = Y[u] = Z[u] = 0.f;
+          if (k < fr.n) { X[u] = s[(size_t)k * 3]; Y[u] = s[(size_t)k * 3 + 1]; Z[u] = s[(size_t)k * 3 + 2]; }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        const int base = base0 + u * 64;
+        if (base >= fr.n || sample >= limit) break;        // wave-uniform
         const int k = base + lane;
         bool hit = false;
-        float lx = 0.f, ly = 0.f, lz = 0.f;
+        const float lx = X[u] - nx, ly = Y[u] - ny, lz = Z[u] - nz;
         int cell = 0;
         if (k < fr.n) {
-            lx = s[(size_t)k * 3] - nx; ly = s[(size_t)k * 3 + 1] - ny; lz = s[(size_t)k * 3 + 2] - nz;
             hit = in_range(lx, ly, lz, maxd, type);
             cell = (int)floorf((lx + maxd) / sx) * gy * gz + (int)floorf((ly + maxd) / sy) * gz + (int)floorf((lz + maxd) / sz);
             cell = cell < 0 ? 0 : (cell > G - 1 ? G - 1 : cell);
@@ -159,23 +197,25 @@ __global__ __launch_bounds__(kBlk) void vector_pool_kernel(const float* __restri
                 const float v = lane == 0 ? hx : (lane == 1 ? hy : hz);
                 ol[g * 3 + lane] = pooling == 0 ? ol[g * 3 + lane] + v : v;
             }
-            if (lane == 0) { gcnt[g] += 1; step[taken * 2] = fr.start + kk; step[taken * 2 + 1] = g; }
+            if (lane == 0) { gcnt[g] += 1; step[(nrec + taken) * 2] = fr.start + kk; step[(nrec + taken) * 2 + 1] = g; }
             wave_lds_sync();                               // gcnt[g] is read by every lane at the next hit
             taken++;
         }
-        if (taken > 0) {
-            int slot = 0;
-            if (lane == 0) slot = atomicAdd(cum, taken);
-            slot = __shfl(slot, 0);
-            if (lane < taken && (long long)slot + lane < cap) {
-                int* o = grouped + ((size_t)slot + lane) * 3;
-                o[0] = step[lane * 2]; o[1] = pt; o[2] = step[lane * 2 + 1];
-            }
-            sample += taken;
-            wave_lds_sync();                               // step[] is rewritten by the next 64 points
+        sample += taken;
+        nrec += taken;
+        if (nrec + 64 > kRecBuf) {                         // the next step could overflow the record buffer: write it out
+            flush_records(step, nrec, pt, grouped, cap, cum, lane);
+            nrec = 0;
         }
+      }
     }
+    if (nrec > 0) flush_records(step, nrec, pt, grouped, cap, cum, lane);
     for (int g = lane; g < G; g += 64) cnt_of_grid[(size_t)pt * G + g] = gcnt[g];
+    if (acc_in_lds) {                                      // coalesced copy-out: a lane reads slots other lanes accumulated
+        wave_lds_sync();
+        for (int e = lane; e < G * ceach; e += 64) newf[(size_t)pt * ceach * G + e] = lacc[e];
+        for (int e = lane; e < G * 3; e += 64) newl[(size_t)pt * 3 * G + e] = lacc[G * ceach + e];
+    }
 }
 
 __global__ __launch_bounds__(256) void vector_pool_grad_kernel(const float* __restrict__ gnew, const int* __restrict__ cnt_of_grid,
@@ -231,15 +271,21 @@ extern "C" int pvx_vector_pool(const float* support_xyz, const float* support_fe
     if (!new_xyz || !xyz_batch_cnt || !new_xyz_batch_cnt || !new_features || !new_local_xyz || !point_cnt_of_grid ||
         (num_max_sum_points > 0 && !grouped_idxs) || (n_support > 0 && (!support_xyz || !support_features)))
         return PVX_ERR_INVALID;
-    PVX_CHECK_HIP(hipMemsetAsync(new_features, 0, sizeof(float) * (size_t)m * G * num_c_each_grid, st));
-    PVX_CHECK_HIP(hipMemsetAsync(new_local_xyz, 0, sizeof(float) * (size_t)m * G * 3, st));
+    size_t lds = (size_t)kWaves * (G + 2 * kRecBuf) * sizeof(int);
+    const size_t with_acc = lds + (size_t)kWaves * G * (num_c_each_grid + 3) * sizeof(float);
+    const int acc_in_lds = with_acc <= 60 * 1024;
+    if (acc_in_lds) {
+        lds = with_acc;                                    // the kernel writes every output element itself
+    } else {
+        PVX_CHECK_HIP(hipMemsetAsync(new_features, 0, sizeof(float) * (size_t)m * G * num_c_each_grid, st));
+        PVX_CHECK_HIP(hipMemsetAsync(new_local_xyz, 0, sizeof(float) * (size_t)m * G * 3, st));
+    }
     const float sx = max_neighbour_distance * 2 / num_grid_x, sy = max_neighbour_distance * 2 / num_grid_y,
                 sz = max_neighbour_distance * 2 / num_grid_z;            // vector_pool_gpu.cu:399-401
-    const size_t lds = (size_t)kWaves * (G + 128) * sizeof(int);
     hipLaunchKernelGGL(vector_pool_kernel, dim3(PVX_CDIV(m, kWaves)), dim3(kBlk), lds, st, support_xyz, support_features, n_support,
                        xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, batch_size, m, num_c_in, num_c_each_grid, num_grid_x, num_grid_y,
                        num_grid_z, max_neighbour_distance, sx, sy, sz, use_xyz, nsample, neighbor_type, pooling_type, new_features,
-                       new_local_xyz, point_cnt_of_grid, grouped_idxs, num_max_sum_points, cum_sum);
+                       new_local_xyz, point_cnt_of_grid, grouped_idxs, num_max_sum_points, cum_sum, acc_in_lds);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

@@ -28,8 +28,10 @@ def sorted_rows(a):
     return a[np.lexsort(a.T[::-1])]
 
 
-@pytest.mark.parametrize("pooling,nsample,ntype,grids", [(0, -1, 0, (3, 3, 3)), (0, 7, 1, (2, 3, 2)), (1, -1, 0, (3, 3, 3)), (1, 5, 1, (4, 4, 1))])
+@pytest.mark.parametrize("pooling,nsample,ntype,grids", [(0, -1, 0, (3, 3, 3)), (0, 7, 1, (2, 3, 2)), (1, -1, 0, (3, 3, 3)), (1, 5, 1, (4, 4, 1)),
+                                                          (0, -1, 0, (8, 8, 8)), (1, -1, 1, (8, 8, 8))])
 def test_vector_pool_vs_oracle(cuda_device, pooling, nsample, ntype, grids):
+    """(8, 8, 8): 512 cells x 19 floats x 4 waves do not fit the LDS accumulator form -> the HBM accumulator form"""
     xyz, feat, xc, new, nc = scene(11, (5000, 1, 3100), (700, 3, 513), 32)
     R, ceach = 1.6, 16
     G = grids[0] * grids[1] * grids[2]
