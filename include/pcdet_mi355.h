@@ -339,6 +339,23 @@ int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prep
                         const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
                         const float* scale, const float* shift, const void* residual, int relu, void* out, void* stream);
 
+/* Tile book: a submanifold / strided rulebook with kvol = 27 re-packed for the slab conv kernels of one window size (no
+ * reference counterpart; spconv keeps its pair tables private too).  Per 256-site tile: the row window of each dz group and
+ * 27 x 256 u16 neighbour rows relative to it (layout: csrc/sparse_conv_slab_tb.h).  Halves the rulebook bytes every conv
+ * layer re-reads and lets the kernel prefetch the next tile's block by LDS-DMA.
+ *   pvx_tilebook_rcap   window rows the tile-book kernel of (cin, cout, kvol, dtype) wants, 0 = that shape has none
+ *   pvx_tilebook_bytes  size of the book for a rulebook of n_out (capacity) columns
+ *   pvx_tilebook_build  nbr [27, n_out] -> book; n_in = rows of the conv's input (entries >= n_in count as absent)
+ * pvx_sparse_conv_fwd_tb = pvx_sparse_conv_fwd with the book of ITS rulebook (built with ITS rcap); tilebook NULL or a
+ * shape without the form falls back to pvx_sparse_conv_fwd's kernels.  Results are bit-identical either way. */
+int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype);
+size_t pvx_tilebook_bytes(int n_out);
+int pvx_tilebook_build(const int* nbr, int kvol, int n_out, const int* n_out_dev, int n_in, int rcap, void* book, void* stream);
+int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                           const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
+                           const float* scale, const float* shift, const void* residual, int relu, void* out,
+                           const void* tilebook, int tilebook_rcap, void* stream);
+
 /* Backward, weight gradient: grad_weight[co, k, ci] (f32, the module parameter's [cout, kvol, cin] layout) =
  * sum over live output rows o of grad_out[o, co] * feat_in[nbr[k][o], ci]; feat_in / grad_out are of `dtype`, fp32
  * accumulation, fixed summation order (partials per site chunk, then one ordered reduction: no float atomics).

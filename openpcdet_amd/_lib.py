@@ -97,6 +97,11 @@ SIGNATURES = {
     "pvx_sparse_conv_prepare_weight": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pvx_sparse_conv_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "pvx_sparse_conv_fwd_tb": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "pvx_tilebook_rcap": (c_int, [c_int, c_int, c_int, c_int]),
+    "pvx_tilebook_bytes": (c_size_t, [c_int]),
+    "pvx_tilebook_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "pvx_sparse_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pvx_sparse_conv_wgrad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),

@@ -669,6 +669,7 @@ int conv_impl() {
 
 #include "sparse_conv_w32.h"
 #include "sparse_conv_slab.h"
+#include "sparse_conv_slab_tb.h"
 #include "sparse_conv_v3.h"
 
 long long prepared_elems(int cout, int K, int cin, int dtype) {
@@ -821,9 +822,10 @@ extern "C" int pvx_sparse_conv_prepare_weight(const void* weight, int cout, int 
     return PVX_OK;
 }
 
-extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
-                                   const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype, const float* scale,
-                                   const float* shift, const void* residual, int relu, void* out, void* stream) {
+static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                         const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype, const float* scale,
+                         const float* shift, const void* residual, int relu, void* out, const void* tilebook, int tilebook_rcap,
+                         void* stream) {
     if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || dtype < 0 || dtype > 2) return PVX_ERR_INVALID;
     if ((scale == nullptr) != (shift == nullptr)) return PVX_ERR_INVALID;
     if (n_out == 0) return PVX_OK;
@@ -842,6 +844,19 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
         PVX_V3_SHAPES(X)
 #undef X
         if (rcv != PVX_OK) return rcv;
+    } else if (tilebook && w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) &&
+               tilebook_rcap > 0 && tilebook_rcap == tilebook_rcap_of(cin, cout, kvol, dtype)) {
+        int rct = PVX_ERR_INVALID;
+#define X(ci, co, rc, sm)                                                                                                     \
+    if (cin == ci && cout == co) {                                                                                            \
+        if (dtype == PVX_BF16)                                                                                                \
+            rct = launch_slab_tb<__bf16, ci, co, rc, sm>(feat_in, n_in, prepared_weight, nbr, tilebook, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+        else                                                                                                                  \
+            rct = launch_slab_tb<_Float16, ci, co, rc, sm>(feat_in, n_in, prepared_weight, nbr, tilebook, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+    }
+        PVX_SLAB_SHAPES(X)
+#undef X
+        if (rct != PVX_OK) return rct;
     } else if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
         int rcs = PVX_ERR_INVALID;
 #define X(ci, co, rc, sm)                                                                                                     \
@@ -883,6 +898,40 @@ extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const
     } else {
         launch_generic<__bf16>(feat_in, n_in, cin, prepared_weight, nbr, kvol, n_out, n_out_dev, cout, bias, scale, shift, residual, relu, out, st);
     }
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                                   const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype, const float* scale,
+                                   const float* shift, const void* residual, int relu, void* out, void* stream) {
+    return conv_fwd_impl(feat_in, n_in, cin, prepared_weight, bias, nbr, kvol, n_out, n_out_dev, cout, dtype, scale, shift, residual, relu,
+                         out, nullptr, 0, stream);
+}
+
+extern "C" int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                                      const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
+                                      const float* scale, const float* shift, const void* residual, int relu, void* out,
+                                      const void* tilebook, int tilebook_rcap, void* stream) {
+    return conv_fwd_impl(feat_in, n_in, cin, prepared_weight, bias, nbr, kvol, n_out, n_out_dev, cout, dtype, scale, shift, residual, relu,
+                         out, tilebook, tilebook_rcap, stream);
+}
+
+extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {
+    return w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) ? tilebook_rcap_of(cin, cout, kvol, dtype) : 0;
+}
+
+extern "C" size_t pvx_tilebook_bytes(int n_out) {
+    return n_out <= 0 ? 256 : (size_t)PVX_CDIV(n_out, kTbTile) * kTbU4 * sizeof(uint4);
+}
+
+extern "C" int pvx_tilebook_build(const int* nbr, int kvol, int n_out, const int* n_out_dev, int n_in, int rcap, void* book,
+                                  void* stream) {
+    if (kvol != kTbK || n_out < 0 || n_in < 0 || rcap <= 0 || rcap >= (int)kTbFar) return PVX_ERR_INVALID;
+    if (n_out == 0) return PVX_OK;
+    if (!nbr || !book) return PVX_ERR_INVALID;
+    hipLaunchKernelGGL(tilebook_kernel, dim3(PVX_CDIV(n_out, kTbTile)), dim3(kTbTile), 0, (hipStream_t)stream, nbr, n_out, n_out_dev, n_in,
+                       rcap, (uint4*)book);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

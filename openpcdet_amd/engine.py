@@ -126,6 +126,13 @@ class HotPathEngine:
         with torch.cuda.device(dev):
             self._build(backbone, level_capacity_factor)
 
+    TILEBOOK_SHAPES = {(16, 16)}
+
+    def _wants_tilebook(self, cin, cout):
+        if self.tilebook_mode == "0":
+            return False
+        return self.tilebook_mode == "all" or (cin, cout) in self.TILEBOOK_SHAPES
+
     # ------------------------------------------------------------------------------------------------------------
     def _feat_buf(self, level, channels, avoid=()):
         """a [cap, channels] buffer of `level` that is none of `avoid` (buffers are recycled within a level)"""
@@ -182,6 +189,12 @@ class HotPathEngine:
         self.vox_ws = _lib.workspace(L.pvx_voxelize_batch_workspace_bytes(B, self.n_pts_cap, self.max_voxels, self.T), dev)
 
         self.ops = []          # (name, callable(stream))
+        self._books = {}       # (rulebook address, window rows) -> tile book buffer
+        # which (cin, cout) layers read their rulebook through a tile book: building one costs about as much as one 16 -> 16
+        # layer saves, so it pays where several rulebook-bound layers share it -- the five 16 -> 16 layers of level 0 (104 -> 68 us
+        # each at B = 16); 32 -> 32 and 64 -> 64 gain 0-3 %, less than their book costs (profiles/r02_tilebook.txt).
+        # PVX_ENGINE_TILEBOOK=0 / all: none / every shape that has the form (A/B switch).
+        self.tilebook_mode = os.environ.get("PVX_ENGINE_TILEBOOK", "1")
         self.conv_records = [] # per conv launch: dict(name, cin, cout, kvol, nbr, level_out) for flop accounting
         keep = []              # keeps ctypes arrays / tensors alive
         self._keep = keep
@@ -211,11 +224,24 @@ class HotPathEngine:
             scale, shift = _fold_bn(spec.bn, cout, dev)
             out = self._feat_buf(level_out, cout, avoid=avoid)
             keep.extend([pw, bias, scale, shift])
+            # tile book of this rulebook for this kernel's window size: built once per (rulebook, window) on the geometry stream,
+            # shared by every conv layer that reads the rulebook with that window (csrc/sparse_conv_slab_tb.h)
+            rcap = L.pvx_tilebook_rcap(cin, cout, kvol, self.code) if self._wants_tilebook(cin, cout) else 0
+            book = None
+            if rcap > 0:
+                bkey = (nbr.data_ptr(), rcap)
+                book = self._books.get(bkey)
+                if book is None:
+                    book = torch.empty(L.pvx_tilebook_bytes(level_out.cap), dtype=torch.uint8, device=dev)
+                    self._books[bkey] = book
+                    ab = (_lib.ptr(nbr), kvol, level_out.cap, _lib.ptr(level_out.n_dev), level_in.cap, rcap, _lib.ptr(book))
+                    self.ops.append(("tilebook", lambda st, a=ab: _lib.check(L.pvx_tilebook_build(*a, st), "pvx_tilebook_build")))
             args = (_lib.ptr(feat_in), level_in.cap, cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr), kvol, level_out.cap,
                     _lib.ptr(level_out.n_dev), cout, self.code, _lib.ptr(scale), _lib.ptr(shift),
-                    _lib.ptr(residual_buf) if residual_buf is not None else None, 1 if spec.relu else 0, _lib.ptr(out))
+                    _lib.ptr(residual_buf) if residual_buf is not None else None, 1 if spec.relu else 0, _lib.ptr(out),
+                    _lib.ptr(book), rcap)
             name = "conv%d_%dx%d_k%d" % (len(self.conv_records), cin, cout, kvol)
-            self.ops.append((name, lambda st, a=args: _lib.check(L.pvx_sparse_conv_fwd(*a, st), "pvx_sparse_conv_fwd")))
+            self.ops.append((name, lambda st, a=args: _lib.check(L.pvx_sparse_conv_fwd_tb(*a, st), "pvx_sparse_conv_fwd_tb")))
             self.conv_records.append(dict(name=name, cin=cin, cin_real=conv.in_channels, cout=cout, kvol=kvol, nbr=nbr,
                                           level_in=level_in, level_out=level_out, subm=conv.subm, residual=residual_buf is not None))
             return out, cout
@@ -309,7 +335,7 @@ class HotPathEngine:
             for name, fn in self.ops:
                 hook(name, lambda: fn(st))
 
-    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook")
+    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook")
 
     def voxelize_ahead(self, stream, load=None, after=None):
         """Voxelize the NEXT batch of this plan on `stream` while another plan's rulebooks are being built: waits for this

@@ -1,0 +1,138 @@
+"""Tile-book form of the slab conv kernels (csrc/sparse_conv_slab_tb.h): the packed book against a numpy restatement of its
+layout, and pvx_sparse_conv_fwd_tb bit-identical to pvx_sparse_conv_fwd (same MFMA order, same epilogue) for every shape that
+has the form -- rows in key order (every neighbour inside the window), rows shuffled (most neighbours outside: the far code
+and its int32 fallback), live rows below the capacity, strided rulebooks; and against the oracle (bf16 bar 1e-2)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from openpcdet_amd import _lib
+from oracle import loader
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64)]
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def sites(seed, batch, shape, n, sort):
+    r = np.random.default_rng(seed)
+    c = np.stack([r.integers(0, batch, n), r.integers(0, shape[0], n), r.integers(0, shape[1], n), r.integers(0, shape[2], n)], 1)
+    c = np.unique(c, axis=0).astype(np.int32)               # np.unique sorts rows lexicographically = key order
+    if not sort:
+        r.shuffle(c, axis=0)
+    return c
+
+
+def book_numpy(nbr, n_live, n_in, rcap):
+    """the layout documented in sparse_conv_slab_tb.h"""
+    K, cap = nbr.shape
+    tiles = (n_live + 255) // 256
+    meta = np.zeros((tiles, 8), np.uint32)
+    ent = np.full((tiles, 27, 256), 0xFFFF, np.uint32)
+    for t in range(tiles):
+        s0, s1 = t * 256, min(t * 256 + 256, n_live)
+        for g in range(3):
+            blk = nbr[g * 9:(g + 1) * 9, s0:s1].astype(np.int64)
+            blk = np.where(blk >= n_in, -1, blk)
+            if (blk >= 0).any():
+                lo, hi = blk[blk >= 0].min(), blk[blk >= 0].max()
+                span = hi - lo + 1
+                cnt = min(span, rcap)
+                wlo = lo if span <= rcap else lo + (span - rcap) // 2
+                meta[t, 2 * g], meta[t, 2 * g + 1] = wlo, cnt
+                meta[t, 6] |= (1 << g) | ((16 << g) if span <= rcap else 0)
+                local = blk - wlo
+                code = np.where(blk < 0, 0xFFFF, np.where((local >= 0) & (local < cnt), local, 0xFFFE))
+                ent[t, g * 9:(g + 1) * 9, :s1 - s0] = code
+    return meta, ent
+
+
+def run_conv(dev, feat, w, nbr_t, n_live_t, cin, cout, code, book=None, rcap=0, residual=None):
+    L = _lib.lib()
+    cap = nbr_t.shape[1]
+    pw = torch.empty(L.pvx_sparse_conv_weight_bytes(cout, 27, cin, code), dtype=torch.uint8, device=dev)
+    _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), cout, 27, cin, code, _lib.ptr(pw), _lib.stream()), "prepare")
+    out = torch.full((cap, cout), 7.0, dtype=feat.dtype, device=dev)
+    scale = torch.linspace(0.5, 1.5, cout, device=dev)
+    shift = torch.linspace(-0.2, 0.2, cout, device=dev)
+    bias = torch.linspace(-0.1, 0.1, cout, device=dev)
+    _lib.check(L.pvx_sparse_conv_fwd_tb(_lib.ptr(feat), feat.shape[0], cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr_t), 27, cap,
+                                        _lib.ptr(n_live_t), cout, code, _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(residual), 1,
+                                        _lib.ptr(out), _lib.ptr(book), rcap, _lib.stream()), "pvx_sparse_conv_fwd_tb")
+    return out, (scale, shift, bias)
+
+
+@pytest.mark.parametrize("cin,cout", SHAPES)
+@pytest.mark.parametrize("sort", [True, False])
+def test_tilebook_conv_bit_identical(cuda_device, cin, cout, sort):
+    L = _lib.lib()
+    dev = cuda_device
+    shape, batch = [12, 60, 56], 2
+    coords = sites(5 + cin, batch, shape, 30000, sort)
+    n = len(coords)
+    cap = n + 300                                            # capacity above the live count
+    nbr = np.full((27, cap), -1, np.int32)
+    nbr[:, :n] = loader.subm_rulebook(coords, shape, (3, 3, 3))
+    r = np.random.default_rng(9)
+    for dtype, code in ((torch.bfloat16, 2), (torch.float16, 1)):
+        rcap = L.pvx_tilebook_rcap(cin, cout, 27, code)
+        assert rcap > 0
+        feat = torch.from_numpy(r.normal(size=(cap, cin)).astype(np.float32)).to(dev).to(dtype)
+        w = torch.from_numpy((r.normal(size=(cout, 27, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev).to(dtype)
+        res = torch.from_numpy(r.normal(size=(cap, cout)).astype(np.float32)).to(dev).to(dtype) if cin == cout else None
+        nbr_t = torch.from_numpy(nbr).to(dev)
+        n_live = torch.tensor([n], dtype=torch.int32, device=dev)
+        book = torch.zeros(L.pvx_tilebook_bytes(cap), dtype=torch.uint8, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, cap, _lib.ptr(n_live), cap, rcap, _lib.ptr(book), _lib.stream()), "build")
+        # the book itself
+        meta, ent = book_numpy(nbr, n, cap, rcap)
+        raw = book.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:meta.shape[0]]
+        assert np.array_equal(raw[:, :7], meta[:, :7])
+        got_ent = raw[:, 8:].copy().view(np.uint16).reshape(-1, 27, 256)
+        assert np.array_equal(got_ent, ent.astype(np.uint16))
+        far = (ent == 0xFFFE).mean()
+        assert (far == 0) if sort else (far > 0.05), far      # sorted rows fit the window; shuffled rows mostly do not
+        # the conv
+        want, (scale, shift, bias) = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, residual=res)
+        got, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, book=book, rcap=rcap, residual=res)
+        assert torch.equal(got[:n], want[:n]), (cin, cout, dtype)
+        assert torch.equal(got[n:], want[n:])                # rows beyond the live count untouched by both
+        if dtype == torch.bfloat16:
+            ref = loader.sparse_conv_fwd(feat[:n].float().cpu().numpy(), w.float().cpu().numpy(), bias.cpu().numpy(), nbr[:, :n])
+            ref = ref * scale.cpu().numpy() + shift.cpu().numpy()
+            if res is not None:
+                ref = ref + res[:n].float().cpu().numpy()
+            assert rel_l2(got[:n].float().cpu().numpy(), np.maximum(ref, 0)) <= 1e-2
+        # a book built for another window size is refused in favour of the plain kernels (still the same result)
+        got2, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, book=book, rcap=rcap + 1, residual=res)
+        assert torch.equal(got2[:n], want[:n])
+
+
+def test_tilebook_strided_rulebook_and_empty(cuda_device):
+    L = _lib.lib()
+    dev = cuda_device
+    shape = [9, 40, 44]
+    coords = sites(31, 2, shape, 15000, True)
+    oc, nbr, oshape = loader.sparse_rulebook(coords, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1])
+    n_out, n_in = nbr.shape[1], len(coords)
+    r = np.random.default_rng(2)
+    feat = torch.from_numpy(r.normal(size=(n_in, 16)).astype(np.float32)).to(dev).bfloat16()
+    w = torch.from_numpy((r.normal(size=(32, 27, 16)) / 20).astype(np.float32)).to(dev).bfloat16()
+    nbr_t = torch.from_numpy(np.ascontiguousarray(nbr)).to(dev)
+    rcap = L.pvx_tilebook_rcap(16, 32, 27, 2)
+    for live in (n_out, 257, 0):
+        n_live = torch.tensor([live], dtype=torch.int32, device=dev)
+        book = torch.zeros(L.pvx_tilebook_bytes(n_out), dtype=torch.uint8, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, n_out, _lib.ptr(n_live), n_in, rcap, _lib.ptr(book), _lib.stream()), "build")
+        want, _ = run_conv(dev, feat, w, nbr_t, n_live, 16, 32, 2)
+        got, _ = run_conv(dev, feat, w, nbr_t, n_live, 16, 32, 2, book=book, rcap=rcap)
+        assert torch.equal(got, want), live
+    assert L.pvx_tilebook_rcap(128, 128, 27, 2) == 0 and L.pvx_tilebook_rcap(16, 16, 27, 0) == 0 and L.pvx_tilebook_rcap(16, 16, 9, 2) == 0
+    assert L.pvx_tilebook_build(None, 9, 10, None, 10, 100, None, None) == -1
