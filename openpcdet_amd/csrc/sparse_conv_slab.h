@@ -14,7 +14,7 @@
 // such as first-come voxel rows, or a tile that straddles two z-planes) falls back to range-checked buffer gathers.
 #pragma once
 
-template <typename E, int CIN, int COUT, int RCAP, int WGS>
+template <typename E, int CIN, int COUT, int RCAP, int WGS, bool PF>
 __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
                                                                const uint4* __restrict__ wfrag, const int* __restrict__ nbr,
                                                                int n_out, const int* __restrict__ n_out_dev,
@@ -87,46 +87,60 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E*
             for (int q = 0; q < 16; q++) acc[t][q] = 0.f;
         const int* my_n = nlds + wave * 32 + col;
 
-        for (int g = 0; g < 3; g++) {
-            const int hi = g_hi[g];
-            if (hi < 0) continue;                          // no pair in this dz group for the whole tile (uniform)
+        // PF (the shapes with register room: one workgroup per CU): the weights and rows of the NEXT dz group that has pairs are
+        // requested before this group's MFMAs and written to LDS after them, so their HBM / L2 round trip runs under the
+        // compute instead of in front of it (the three window spans of a tile are known from the start).
+        constexpr int NW = (GK * TL::GROUP_U4 + NT - 1) / NT, NR = (RCAP * ROW_U4 + NT - 1) / NT;
+        u32x4 wt[NW], rt[NR];                              // native vectors: a loop-carried array of HIP's uint4 struct stays an alloca
+        auto window_of = [&](int g, int& lo, int& cnt) {
+            const int span = g_hi[g] - g_lo[g] + 1;
+            cnt = span <= RCAP ? span : RCAP;
+            lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
+        };
+        auto request = [&](int g) __attribute__((always_inline)) {
+            int lo, cnt;
+            window_of(g, lo, cnt);
+            const int chunks = cnt * ROW_U4;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const int i = q * NT + tid;
+                wt[q] = u32x4{0u, 0u, 0u, 0u};
+                if (i < GK * TL::GROUP_U4) wt[q] = reinterpret_cast<const u32x4*>(wfrag)[(size_t)g * GK * TL::GROUP_U4 + i];
+            }
+#pragma unroll
+            for (int q = 0; q < NR; q++) {
+                const int c = q * NT + tid;
+                rt[q] = u32x4{0u, 0u, 0u, 0u};
+                if (c < chunks) rt[q] = reinterpret_cast<const u32x4*>(feat_u4)[(size_t)lo * ROW_U4 + c];
+            }
+        };
+        auto next_group = [&](int g) { g++; while (g < 3 && g_hi[g] < 0) g++; return g; };
+        int g_first = next_group(-1);
+        if (PF && g_first < 3) request(g_first);
+
+        for (int g = g_first; g < 3; g = next_group(g)) {
             // rows [lo, lo + cnt) go to LDS; when the span is longer than the LDS window, the window is centred in it and the
             // sites whose neighbour falls outside read theirs with a buffer gather instead (per lane)
-            const int span = g_hi[g] - g_lo[g] + 1;
-            const int cnt = span <= RCAP ? span : RCAP;
-            const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
-            const bool all_in = span <= RCAP;
+            int lo, cnt;
+            window_of(g, lo, cnt);
+            const bool all_in = g_hi[g] - g_lo[g] + 1 <= RCAP;
             __syncthreads();                               // the previous group's MFMAs are done with wlds / rlds
             {
-                constexpr int NW = (GK * TL::GROUP_U4 + NT - 1) / NT;
-                uint4 wt[NW];
-#pragma unroll
-                for (int q = 0; q < NW; q++) {
-                    const int i = q * NT + tid;
-                    wt[q] = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < GK * TL::GROUP_U4) wt[q] = wfrag[(size_t)g * GK * TL::GROUP_U4 + i];
-                }
-                constexpr int NR = (RCAP * ROW_U4 + NT - 1) / NT;
-                uint4 rt[NR];
+                if (!PF) request(g);
                 const int chunks = cnt * ROW_U4;
 #pragma unroll
-                for (int q = 0; q < NR; q++) {
-                    const int c = q * NT + tid;
-                    rt[q] = make_uint4(0u, 0u, 0u, 0u);
-                    if (c < chunks) rt[q] = feat_u4[(size_t)lo * ROW_U4 + c];
-                }
-#pragma unroll
                 for (int q = 0; q < NW; q++) {
                     const int i = q * NT + tid;
-                    if (i < GK * TL::GROUP_U4) wlds[i] = wt[q];
+                    if (i < GK * TL::GROUP_U4) reinterpret_cast<u32x4*>(wlds)[i] = wt[q];
                 }
 #pragma unroll
                 for (int q = 0; q < NR; q++) {
                     const int c = q * NT + tid;
-                    if (c < chunks) { const int row = c / ROW_U4; rlds[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
+                    if (c < chunks) { const int row = c / ROW_U4; reinterpret_cast<u32x4*>(rlds)[row * RS_U4 + (c - row * ROW_U4)] = rt[q]; }
                 }
             }
             __syncthreads();
+            if (PF) { const int gn = next_group(g); if (gn < 3) request(gn); }
             // The nine offsets of the group as ONE software pipeline: all nine rulebook entries are read first, the B rows of
             // offset kk + 1 (LDS reads, plus the gather of lanes outside the window) are issued before the MFMAs of offset kk,
             // and the A fragments of flat step j + 1 are fetched during the MFMAs of step j, across offset boundaries.  Left to the
@@ -484,6 +498,12 @@ inline bool slab_enabled() {
     return v != 0;
 }
 
+inline bool slab_prefetch() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PVX_SLAB_PREFETCH"); v = e ? atoi(e) : 1; }   // PVX_SLAB_PREFETCH=0: A/B switch
+    return v != 0;
+}
+
 inline bool slab_shape(int cin, int cout, int K, int dtype) {
     if (dtype == PVX_F32 || K != 27 || !slab_enabled()) return false;
 #define X(ci, co, rc, st) if (cin == ci && cout == co) return true;
@@ -505,9 +525,19 @@ int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n
                            (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
                            relu, (E*)out);
     } else {
-        hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP, (STREAM == 3 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
-                           (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
-                           relu, (E*)out);
+        bool done = false;
+        if constexpr (STREAM == 0) {
+            if (slab_prefetch()) {
+                hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP, 1, true>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                                   (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
+                                   relu, (E*)out);
+                done = true;
+            }
+        }
+        if (!done)
+            hipLaunchKernelGGL((sparse_conv_slab_kernel<E, CIN, COUT, RCAP, (STREAM == 3 ? 2 : 1), false>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                               (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
+                               relu, (E*)out);
     }
     return PVX_OK;
 }
