@@ -102,6 +102,8 @@ def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts, single_thread_fr
 def conv_kernel_name(cin, cout, kvol):
     if os.environ.get("PVX_CONV_V3", "0") != "0" and kvol == 27 and (cin, cout) in ((64, 64), (128, 128), (64, 128)):
         return "sparse_conv_v3_kernel<bf16,%d,%d>" % (cin, cout)
+    if kvol == 27 and (cin, cout) in engine.HotPathEngine.TILEBOOK_SHAPES and os.environ.get("PVX_ENGINE_TILEBOOK", "1") == "1":
+        return "sparse_conv_slab_tb_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in ((16, 16), (16, 32), (32, 32), (32, 64), (64, 64)):
         return "sparse_conv_slab_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in ((64, 128), (128, 64), (128, 128)):
