@@ -123,7 +123,11 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E*
             // sites whose neighbour falls outside read theirs with a buffer gather instead (per lane)
             int lo, cnt;
             window_of(g, lo, cnt);
+#ifdef PVX_SLAB_ABL_NOFALLBACK
+            const bool all_in = true;                      // timing ablation only: neighbours outside the window read zeros
+#else
             const bool all_in = g_hi[g] - g_lo[g] + 1 <= RCAP;
+#endif
             __syncthreads();                               // the previous group's MFMAs are done with wlds / rlds
             {
                 if (!PF) request(g);
@@ -328,7 +332,11 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
             const int span = g_hi[g] - g_lo[g] + 1;
             const int cnt = span <= RCAP ? span : RCAP;
             const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
+#ifdef PVX_SLAB_ABL_NOFALLBACK
+            const bool all_in = true;
+#else
             const bool all_in = span <= RCAP;
+#endif
             __syncthreads();                               // the previous group is done with wlds / rlds / nlds
             {
                 constexpr int NG = (GK * TM + NT - 1) / NT;
