@@ -70,7 +70,7 @@ size_t pvx_nms_workspace_bytes(int n_cap, int segments);
  *   normal = 1: axis-aligned IoU  (nms_normal_gpu, iou3d_nms.cpp:186-233 -> nms_normal_kernel, kernel.cu:356-400)
  * keep[0 .. *num_keep) receives the kept indices (ascending, int64 like the reference's `long`), both on the
  * DEVICE: unlike the reference there is no device->host copy of the mask and no host loop.
- * n <= 65536 (PVX_ERR_RANGE beyond). */
+ * n <= 262144 (PVX_ERR_RANGE beyond; the mask workspace is n * ceil(n / 64) * 8 bytes, 8.6 GB at that size). */
 int pvx_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep,
             void* workspace, size_t workspace_bytes, void* stream);
 

@@ -21,7 +21,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxColBlocks = 1024;   // n <= 65536 boxes per NMS problem
+constexpr int kMaxColBlocks = 4096;   // n <= 262144 boxes per NMS problem (the scan's removal mask: 32 KiB of LDS)
 
 // per-thread polygon vertex scratch in LDS, laid out [slot][thread] so lanes hit distinct banks
 struct VertexScratch {

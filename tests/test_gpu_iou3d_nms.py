@@ -222,3 +222,19 @@ def test_nms_select_limits(cuda_device):
     rc = L.pvx_nms_select_batched(_lib.ptr(b), 6, _lib.ptr(s), None, 1, 64, float("-inf"), 0, 0.5, 0, 10, _lib.ptr(sel), _lib.ptr(num),
                                   _lib.ptr(ws), ws.numel(), None)
     assert rc == -1                                   # PVX_ERR_INVALID: rows narrower than a box
+
+
+def test_nms_above_65536_boxes(cuda_device):
+    """the reference has no 65536-box limit.  70000 boxes = 35000 well-separated boxes + an exact lower-scored copy of each:
+    the kept set is known without an O(n^2) CPU check -- every original, in score order, and no copy."""
+    rng = np.random.default_rng(41)
+    m = 35000
+    gx, gy = np.meshgrid(np.arange(200), np.arange(175))
+    centers = np.stack([gx.ravel()[:m] * 6.0, gy.ravel()[:m] * 6.0], 1)
+    base = np.c_[centers, rng.uniform(-1, 1, m), rng.uniform(1.5, 4.0, (m, 2)), rng.uniform(1, 2, m), rng.uniform(-3, 3, m)].astype(np.float32)
+    boxes = np.concatenate([base, base])
+    scores = np.concatenate([rng.permutation(m) + m, rng.permutation(m)]).astype(np.float32)     # every original outranks every copy
+    sel, _ = U.nms_gpu(torch.from_numpy(boxes).to(cuda_device), torch.from_numpy(scores).to(cuda_device), 0.5)
+    sel = sel.cpu().numpy()
+    assert sel.size == m and sel.max() < m
+    assert np.array_equal(sel, np.argsort(-scores[:m], kind="stable"))
