@@ -70,18 +70,23 @@ __device__ __forceinline__ s16x8 read_operand(const unsigned char* tile, int lan
 
 // one wave per workgroup; unit = blockIdx.x = chunk * K + k.  RAGGED: the input rows hold cin_rt < CIN = 32 channels (the
 // backbone's first layer: 4..6 point features), gathered element by element into the zero-padded 32-channel tile.
-template <typename E, int CIN, int COUT, bool RAGGED>
+// CSPLIT > 1: the output channels are cut into CSPLIT slices of COUT / CSPLIT, one wave each (128 x 128 as one wave needs 256
+// accumulator registers plus staging and spills; two waves of 64 x 128 do not, and twice as many waves are in flight).
+template <typename E, int CIN, int COUT, bool RAGGED, int CSPLIT = 1>
 __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ feat_in, int n_in, const E* __restrict__ gout,
                                                          const int* __restrict__ nbr, int kvol, int n_out_cap,
                                                          const int* __restrict__ n_out_dev, int rows_per_chunk,
                                                          float* __restrict__ partial, int cin_rt) {
-    typedef TileGeo<COUT> GO;
+    constexpr int CT = COUT / CSPLIT;
+    typedef TileGeo<CT> GO;
     typedef TileGeo<CIN> GI;
     __shared__ __attribute__((aligned(16))) unsigned char lds[GO::BYTES + GI::BYTES];
     unsigned char* const tile_o = lds;
     unsigned char* const tile_i = lds + GO::BYTES;
     const int lane = threadIdx.x;
-    const int k = blockIdx.x % kvol, chunk = blockIdx.x / kvol;
+    const int slice = blockIdx.x % CSPLIT, unit = blockIdx.x / CSPLIT;
+    const int k = unit % kvol, chunk = unit / kvol;
+    gout += slice * CT;                                    // this wave's columns of every gout row (row stride stays COUT)
     const int n_out = live_rows(n_out_cap, n_out_dev);
     const int row_begin = chunk * rows_per_chunk;
     if (row_begin >= n_out) return;                       // the reduction pass skips these chunks too
@@ -98,6 +103,76 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ fe
             for (int j = 0; j < 16; j++) acc[a][b][j] = 0.f;
 
     const int* __restrict__ nbr_k = nbr + (size_t)k * n_out_cap;
+    if constexpr (!RAGGED) {
+        // Two-deep software pipeline over the unit's 32-site tiles: the rulebook entries of tile t + 2 and the rows of tile t + 1
+        // are in flight while tile t goes registers -> LDS -> MFMA (one wave per workgroup: nothing else hides the round trips).
+        // The staging registers are reused in place (stored to LDS, then reloaded), so the pipeline costs no extra registers.
+        typedef __attribute__((ext_vector_type(4))) unsigned v4u;     // native vectors: loop-carried HIP uint4 arrays become allocas
+        constexpr int IT_O = (kTileRows * GO::CHUNKS + 63) / 64, IT_I = (kTileRows * GI::CHUNKS + 63) / 64;
+        v4u vo[IT_O], vi[IT_I];
+        auto load_src = [&](int r0) {
+            const int my_row = r0 + (lane & 31);
+            int v = -1;
+            if (r0 < row_end && my_row < row_end) { v = nbr_k[my_row]; if (v >= n_in) v = -1; }
+            return v;
+        };
+        auto request_rows = [&](int r0, int my_src) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < IT_O; it++) {
+                const int c = it * 64 + lane, row = c / GO::CHUNKS, cc = c % GO::CHUNKS;
+                vo[it] = v4u{0u, 0u, 0u, 0u};
+                if (row < kTileRows && r0 + row < row_end)
+                    vo[it] = *reinterpret_cast<const v4u*>(gout + (size_t)(r0 + row) * COUT + cc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < IT_I; it++) {
+                const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
+                const int src = __shfl(my_src, row & 31);
+                vi[it] = v4u{0u, 0u, 0u, 0u};
+                if (row < kTileRows && src >= 0) vi[it] = *reinterpret_cast<const v4u*>(feat_in + (size_t)src * CIN + cc * 8);
+            }
+        };
+        int src_cur = load_src(row_begin), src_next = load_src(row_begin + kTileRows);
+        bool any_cur = __ballot(src_cur >= 0) != 0ull;
+        if (any_cur) request_rows(row_begin, src_cur);
+        for (int r0 = row_begin; r0 < row_end; r0 += kTileRows) {
+            const int src_after = load_src(r0 + 2 * kTileRows);
+            const bool any_next = __ballot(src_next >= 0) != 0ull;          // wave-uniform
+            if (any_cur) {
+#pragma unroll
+                for (int it = 0; it < IT_O; it++) {
+                    const int c = it * 64 + lane, row = c / GO::CHUNKS, cc = c % GO::CHUNKS;
+                    if (row < kTileRows) *reinterpret_cast<v4u*>(tile_o + row * GO::STRIDE + cc * 16) = vo[it];
+                }
+#pragma unroll
+                for (int it = 0; it < IT_I; it++) {
+                    const int c = it * 64 + lane, row = c / GI::CHUNKS, cc = c % GI::CHUNKS;
+                    if (row < kTileRows) *reinterpret_cast<v4u*>(tile_i + row * GI::STRIDE + cc * 16) = vi[it];
+                }
+            }
+            if (any_next) request_rows(r0 + kTileRows, src_next);           // in flight during the MFMAs below
+            if (any_cur) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    s16x8 a[GO::TILES], b[GI::TILES];
+#pragma unroll
+                    for (int t = 0; t < GO::TILES; t++) a[t] = read_operand<GO::STRIDE>(tile_o, lane, s, t);
+#pragma unroll
+                    for (int t = 0; t < GI::TILES; t++) b[t] = read_operand<GI::STRIDE>(tile_i, lane, s, t);
+#pragma unroll
+                    for (int to = 0; to < GO::TILES; to++)
+#pragma unroll
+                        for (int ti = 0; ti < GI::TILES; ti++) acc[to][ti] = MfmaT<E>::run(a[to], b[ti], acc[to][ti]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next tile's stores must not pass these reads
+                __builtin_amdgcn_wave_barrier();
+            }
+            src_cur = src_next; src_next = src_after; any_cur = any_next;
+        }
+    } else
     for (int r0 = row_begin; r0 < row_end; r0 += kTileRows) {
         const int my_row = r0 + (lane & 31);
         int my_src = -1;
@@ -173,7 +248,7 @@ __global__ __launch_bounds__(64) void wgrad_mfma_kernel(const E* __restrict__ fe
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int co = 32 * to + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3), ci = 32 * ti + (lane & 31);
-                if (co < COUT && ci < cin) dst[(size_t)co * cin + ci] = acc[to][ti][j];
+                if (co < CT && ci < cin) dst[(size_t)(slice * CT + co) * cin + ci] = acc[to][ti][j];
             }
 }
 
@@ -240,8 +315,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (t >= per) return;
     const int n_out = live_rows(n_out_cap, n_out_dev);
     const int chunks = (n_out + rows_per_chunk - 1) / rows_per_chunk;
+    // chunk order is the summation order (deterministic); eight loads are in flight per thread instead of one
     float s = 0.f;
-    for (int c = 0; c < chunks; c++) s += partial[(size_t)c * per + t];
+    int c = 0;
+    for (; c + 8 <= chunks; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(c + u) * per + t];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; c < chunks; c++) s += partial[(size_t)c * per + t];
     const int ci = (int)(t % cin);
     const int co = (int)((t / cin) % cout);
     const int k = (int)(t / ((long long)cin * cout));
@@ -274,8 +358,9 @@ int launch_mfma(const void* feat_in, int n_in, int cin, const void* gout, const 
                 int cout, int rpc, float* partial, unsigned units, hipStream_t st) {
 #define X(CI, CO)                                                                                                              \
     if (cin == CI && cout == CO) {                                                                                             \
-        hipLaunchKernelGGL((wgrad_mfma_kernel<E, CI, CO, false>), dim3(units), dim3(64), 0, st, (const E*)feat_in, n_in,          \
-                           (const E*)gout, nbr, kvol, n_out, n_out_dev, rpc, partial, CI);                                     \
+        constexpr int SPLIT = (CI * CO >= 64 * 128) ? 2 : 1;                                                                   \
+        hipLaunchKernelGGL((wgrad_mfma_kernel<E, CI, CO, false, SPLIT>), dim3(units * SPLIT), dim3(64), 0, st, (const E*)feat_in, \
+                           n_in, (const E*)gout, nbr, kvol, n_out, n_out_dev, rpc, partial, CI);                               \
         PVX_CHECK_LAUNCH();                                                                                                    \
         return PVX_OK;                                                                                                         \
     }
