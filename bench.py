@@ -122,8 +122,6 @@ def main():
     ap.add_argument("--geo-after", type=int, default=9,
                     help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 8..11 measured "
                          "best for this backbone with the in-kernel NMS front end: profiles/r02_schedule_sweep.txt)")
-    ap.add_argument("--geometry-cus", type=int, default=0,
-                    help="CUs reserved for the geometry / NMS streams (CU-masked streams; 0 = shared CUs, priority streams)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
     ap.add_argument("--nms-stream", default="own", choices=("own", "vox"), help="stream of the NMS launches: its own, or the voxelizer's")
@@ -280,12 +278,6 @@ def main():
     # the convolutions are the critical path: they get the high-priority stream, geometry and NMS fill in around them
     lo, hi = torch.cuda.Stream.priority_range()
     conv_stream = torch.cuda.Stream(device=dev, priority=hi) if (pipelined and not args.flat_priority) else torch.cuda.current_stream(dev)
-    if pipelined and args.geometry_cus > 0:
-        # disjoint CU sets: the geometry of batch i+1 and the NMS never sit on a CU a conv workgroup is waiting for
-        conv_stream, geo_stream = engine.cu_partition_streams(dev, args.geometry_cus)
-        eng.use_geometry_stream(geo_stream)
-        eng2.use_geometry_stream(geo_stream)
-        nms_stream = geo_stream
     conv_stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(conv_stream):
         if vox_ahead:      # the first batch's voxelization; from then on every step voxelizes the batch after its own
@@ -449,7 +441,7 @@ def main():
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
                        "hip_graph": graph is not None, "streams": 1 if args.no_overlap else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
-                       "geometry_cus": args.geometry_cus if pipelined else 0, "voxelize_ahead": bool(vox_ahead), "geo_after": args.geo_after, "rows_per_level": rows},
+                       "voxelize_ahead": bool(vox_ahead), "geo_after": args.geo_after, "rows_per_level": rows},
             "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu, "checked": checked,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),
                        "dense_ms": round(dense_ms, 4), "nms_ms": round(nms_ms, 4)},

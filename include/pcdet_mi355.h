@@ -36,11 +36,6 @@ extern "C" {
 /* library identity: returns a static string "pcdet_mi355 <version> gfx950" (host) */
 const char* pvx_version(void);
 
-/* A stream restricted to the CUs whose bits are set in mask_words (bit i of word i / 32; MI355X has 256 CUs = 8 words),
- * and its release.  Used by the serving loop to keep the geometry kernels of the next batch off the CUs the persistent
- * conv kernels occupy (pvx_sparse_conv_set_cu_budget).  No counterpart in the reference. */
-int pvx_stream_create_cu_mask(const unsigned* mask_words, int n_words, void** stream_out);
-int pvx_stream_destroy(void* stream);
 /* last hipError_t recorded by a call that returned PVX_ERR_HIP (host) */
 int pvx_last_hip_error(void);
 
@@ -318,11 +313,6 @@ int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd, int n_in_f
 /* HOST: 1 when (cin, cout, dtype) runs on the MFMA implicit-GEMM kernel, 0 when on the generic fp32-math kernel. */
 int pvx_sparse_conv_uses_mfma(int cin, int cout, int dtype);
 
-/* Number of CUs the persistent conv kernels occupy (0 = all; rounded down to a multiple of 8, the same share of every
- * XCD).  A conv workgroup fills its CU's registers and LDS, so kernels of other streams only run on CUs the convs leave
- * free: a serving loop that overlaps the next batch's voxelization / rulebooks with this batch's convs sets e.g. 224.
- * Process-wide, read at every launch.  No counterpart in the reference (spconv sizes its grids to the problem). */
-int pvx_sparse_conv_set_cu_budget(int cus);
 /* HOST: bytes of the kernel-ready copy of a [cout, kvol, cin] weight. */
 size_t pvx_sparse_conv_weight_bytes(int cout, int kvol, int cin, int dtype);
 /* Re-lay a [cout, kvol, cin] weight (the module's parameter, dtype PVX_*) into the kernel's fragment order.

@@ -23,8 +23,6 @@ c_void_p, c_int, c_float, c_size_t, c_int64 = ctypes.c_void_p, ctypes.c_int, cty
 # name -> (restype, argtypes); must list every symbol include/pcdet_mi355.h declares
 SIGNATURES = {
     "pvx_version": (ctypes.c_char_p, []),
-    "pvx_stream_create_cu_mask": (c_int, [c_void_p, c_int, c_void_p]),
-    "pvx_stream_destroy": (c_int, [c_void_p]),
     "pvx_last_hip_error": (c_int, []),
     "pvx_boxes_overlap_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
@@ -71,7 +69,6 @@ SIGNATURES = {
     "pvx_scatter_sum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_unique_sites": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_size_t, c_void_p]),
-    "pvx_sparse_conv_set_cu_budget": (c_int, [c_int]),
     "pvx_center_decode": (c_int, [c_void_p] * 6 + [ctypes.c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pvx_voxel_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int, c_int, c_int, ctypes.c_float] +

@@ -627,10 +627,9 @@ template <int CIN, int COUT> long long frag_elems(int K) {
     return (long long)TL::groups(K) * TL::GROUP_U4 * 8;
 }
 
-// CUs the persistent conv kernels spread over.  Their workgroups fill a CU's registers and LDS, so nothing else can run on a
-// CU while a conv kernel holds it; a budget below the chip's CU count (pvx_sparse_conv_set_cu_budget, or PVX_CONV_CUS)
-// leaves the remaining CUs of every XCD to the kernels of other streams (the geometry stream of the next batch).
-int g_cu_budget = 0;   // 0 = all
+// CUs the persistent conv kernels spread over, rounded up to a multiple of 8: the XCD-aware tile walk gives every XCD the same
+// number of workgroups.  (Round 1 measured a smaller budget with the geometry on CU-masked streams of its own: a loss,
+// profiles/r01_d_conv_variants.txt; the knobs are gone.)
 int num_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -638,11 +637,8 @@ int num_cus() {
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         else cus = 256;
-        const char* e = getenv("PVX_CONV_CUS");
-        if (e && g_cu_budget == 0) g_cu_budget = atoi(e);
     }
-    if (g_cu_budget >= 8 && g_cu_budget < cus) return g_cu_budget / 8 * 8;   // the same number in each of the 8 XCDs
-    return (cus + 7) / 8 * 8;   // grids are multiples of 8: the XCD-aware tile walk gives every XCD the same number of workgroups
+    return (cus + 7) / 8 * 8;
 }
 
 // timing-only ablation (cdna_hip_programming.md section 7): PVX_ABLATE_GATHER=1 gives the feature buffer descriptor
@@ -766,12 +762,6 @@ extern "C" int pvx_debug_conv_stamps(unsigned long long* host_out, int n_words) 
 }
 
 extern "C" int pvx_sparse_conv_uses_mfma(int cin, int cout, int dtype) { return mfma_shape(cin, cout, dtype) ? 1 : 0; }
-
-extern "C" int pvx_sparse_conv_set_cu_budget(int cus) {
-    if (cus < 0) return PVX_ERR_INVALID;
-    g_cu_budget = cus;
-    return PVX_OK;
-}
 
 extern "C" size_t pvx_sparse_conv_weight_bytes(int cout, int kvol, int cin, int dtype) {
     if (cout <= 0 || kvol <= 0 || cin <= 0 || dtype < 0 || dtype > 2) return 0;

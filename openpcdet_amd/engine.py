@@ -433,7 +433,7 @@ class HotPathEngine:
             return self._geo_stream()
 
     def use_geometry_stream(self, stream):
-        """run the geometry launches on `stream` (e.g. a CU-masked stream from `cu_partition_streams`) instead of a
+        """run the geometry launches on `stream` instead of a
         stream of the plan's own; call before the first forward(overlap=True)"""
         with torch.cuda.device(self.device):
             self._geo_stream()
@@ -514,38 +514,3 @@ class BatchedNMS:
         valid = self._idx[:, :self.post_max] < self.num.view(-1, 1)
         sel = torch.gather(order, 1, torch.where(valid, k, torch.zeros_like(k)))
         return sel, torch.clamp(self.num, max=self.post_max)
-
-
-def cu_partition_streams(device, geometry_cus, total_cus=None):
-    """Two HIP streams with disjoint CU masks: (conv_stream, geometry_stream).  `geometry_cus` CUs (a multiple of 8: the
-    same share of each XCD -- the mask bits of gfx942 / gfx950 are dealt to the XCDs round-robin) go to the geometry
-    stream, the rest to the conv stream, and the persistent conv kernels are told to size their grids for what is left
-    (pvx_sparse_conv_set_cu_budget).  A conv workgroup fills its CU, so on shared CUs geometry waves delay conv
-    workgroups one for one; on CUs of their own they do not."""
-    L = _lib.lib()
-    device = torch.device(device)
-    total = torch.cuda.get_device_properties(device).multi_processor_count if total_cus is None else int(total_cus)
-    g = int(geometry_cus) // 8 * 8
-    assert 0 < g < total
-    words = (total + 31) // 32
-    conv_bits, geo_bits = [0] * words, [0] * words
-    for i in range(total):
-        (geo_bits if i >= total - g else conv_bits)[i // 32] |= 1 << (i % 32)
-    streams = []
-    with torch.cuda.device(device):
-        for bits in (conv_bits, geo_bits):
-            arr = (ctypes.c_uint * words)(*bits)
-            out = ctypes.c_void_p()
-            _lib.check(L.pvx_stream_create_cu_mask(arr, words, ctypes.byref(out)), "pvx_stream_create_cu_mask")
-            streams.append(torch.cuda.ExternalStream(out.value, device=device))
-    _lib.check(L.pvx_sparse_conv_set_cu_budget(total - g), "pvx_sparse_conv_set_cu_budget")
-    return streams[0], streams[1]
-
-
-def release_cu_partition(conv_stream, geometry_stream):
-    """destroy the two streams of `cu_partition_streams` (after synchronising them) and give the convs the whole chip back"""
-    L = _lib.lib()
-    for st in (conv_stream, geometry_stream):
-        st.synchronize()
-        _lib.check(L.pvx_stream_destroy(ctypes.c_void_p(st.cuda_stream)), "pvx_stream_destroy")
-    _lib.check(L.pvx_sparse_conv_set_cu_budget(0), "pvx_sparse_conv_set_cu_budget")

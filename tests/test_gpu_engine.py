@@ -391,28 +391,3 @@ def test_voxelize_ahead_cu_budget_and_masked_streams(cuda_device):
     got = eng.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
     torch.cuda.synchronize()
     assert torch.equal(got, want[0])
-    # 2. conv CU budget: fewer, longer-running workgroups, same sums
-    try:
-        assert L.pvx_sparse_conv_set_cu_budget(64) == 0
-        eng.load_points(to_dev(frames_a))
-        got = eng.forward(overlap=False).clone()
-        torch.cuda.synchronize()
-        assert torch.equal(got, want[0])
-        assert L.pvx_sparse_conv_set_cu_budget(-1) != 0
-    finally:
-        L.pvx_sparse_conv_set_cu_budget(0)
-    # 3. CU-masked streams (conv on one CU set, geometry on the rest); the helper also sets the budget
-    try:
-        conv_s, geo_s = engine.cu_partition_streams(cuda_device, 64)
-        eng.use_geometry_stream(geo_s)
-        conv_s.wait_stream(torch.cuda.current_stream(cuda_device))
-        with torch.cuda.stream(conv_s):
-            eng.load_points(to_dev(frames_b))
-            got = eng.forward(overlap=True).clone()
-        torch.cuda.synchronize()
-        assert torch.equal(got, want[1])
-        eng.use_geometry_stream(torch.cuda.Stream(device=cuda_device))
-        engine.release_cu_partition(conv_s, geo_s)
-    finally:
-        L.pvx_sparse_conv_set_cu_budget(0)
-    assert L.pvx_stream_create_cu_mask(None, 0, None) != 0
