@@ -439,6 +439,40 @@ int pvx_vector_pool_grad(const float* grad_new_features, const int* point_cnt_of
                          long long num_entries, int m, int n_support, int num_c_in, int num_c_each_grid,
                          int num_total_grids, float* grad_support_features, void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm1d over a sparse tensor's [n, c] feature matrix fused with (+ residual) -> ReLU: the
+ * norm_fn -> ReLU tail of post_act_block (spconv_backbone.py:21-25) and bn -> (+= identity) -> relu of
+ * SparseBasicBlock.forward (:52-64) in the training step (BASELINE.json configs[3]).  dtype = PVX_F32 / F16 / BF16 for x, y,
+ * residual, dy, dx, dres; gamma, beta, statistics and their gradients are f32.  c must be a multiple of 16 bytes of elements
+ * and <= 128 (pvx_bn_act_supported).  Semantics of torch.nn.functional.batch_norm(training=True): biased batch variance for
+ * the normalisation, running statistics (NULL = not tracked) updated with `momentum` and the unbiased variance.
+ *   fwd: y = relu?(gamma (x - mean) invstd + beta (+ residual)); save_mean / save_invstd [c] are kept for the backward pass
+ *   bwd: g = dy masked by y > 0 (when relu); dbeta = sum g, dgamma = sum g xhat,
+ *        dx = gamma invstd (g - mean(g) - xhat mean(g xhat)), dres = g (NULL = no residual)
+ * ---------------------------------------------------------------------------------------------------- */
+int pvx_bn_act_supported(int c, int dtype);
+size_t pvx_bn_act_workspace_bytes(int c);
+int pvx_bn_act_fwd(const void* x, int n, int c, int dtype, const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, const void* residual, int relu, void* y, float* save_mean,
+                   float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
+int pvx_bn_act_bwd(const void* dy, const void* x, const void* y, int n, int c, int dtype, const float* gamma,
+                   const float* save_mean, const float* save_invstd, int relu, void* dx, void* dres, float* dgamma,
+                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same two ops for SyncBatchNorm (tools/train.py:130-131): statistics over the rows of ALL ranks.  phase 1 leaves the local
+ * column sums in sums[2 c + 1] (f64, device; forward: sum x, sum x^2; backward: sum g, sum g xhat, and dbeta / dgamma = the LOCAL
+ * sums, which DDP averages like every other parameter gradient; the last entry = the local row count) and returns; the caller
+ * all-reduces `sums` over its process group (RCCL) and calls again with phase 2, which finishes over n_total rows (n_total <= 0: the
+ * all-reduced count in sums[2 c], no host read) and applies.  phase 0 is pvx_bn_act_fwd / _bwd. */
+int pvx_bn_act_fwd_sync(const void* x, int n, int c, int dtype, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, const void* residual, int relu, void* y,
+                        float* save_mean, float* save_invstd, double* sums, long long n_total, int phase, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int pvx_bn_act_bwd_sync(const void* dy, const void* x, const void* y, int n, int c, int dtype, const float* gamma,
+                        const float* save_mean, const float* save_invstd, int relu, void* dx, void* dres, float* dgamma,
+                        float* dbeta, double* sums, long long n_total, int phase, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

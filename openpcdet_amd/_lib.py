@@ -41,6 +41,16 @@ SIGNATURES = {
                                 c_void_p]),
     "pvx_vector_pool_grad": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
+    "pvx_bn_act_supported": (c_int, [c_int, c_int]),
+    "pvx_bn_act_workspace_bytes": (c_size_t, [c_int]),
+    "pvx_bn_act_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_bn_act_fwd_sync": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
+    "pvx_bn_act_bwd_sync": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
+    "pvx_bn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_nms_static": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev_cpu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

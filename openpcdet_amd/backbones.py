@@ -69,12 +69,12 @@ class SparseBasicBlock(spconv.SparseModule):
         self.stride = stride
 
     def forward(self, x):
+        from .spconv.pytorch.norm import bn_act      # fused BN (+ identity) + ReLU in training mode, the modules themselves otherwise
         out = self.conv1(x)
-        out = out.replace_feature(self.relu(self.bn1(out.features)))
+        out = out.replace_feature(bn_act(out.features, self.bn1, relu=True))
         out = self.conv2(out)
-        out = out.replace_feature(self.bn2(out.features))
         identity = x if self.downsample is None else self.downsample(x)
-        return out.replace_feature(self.relu(out.features + identity.features))
+        return out.replace_feature(bn_act(out.features, self.bn2, residual=identity.features, relu=True))
 
 
 def _sparse_shape(grid_size):

@@ -63,15 +63,26 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for module in self._modules.values():
+        from . import norm
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input = input.replace_feature(module(input.features))
+                    # BatchNorm1d -> ReLU in training mode: one fused op (csrc/batchnorm.hip) instead of six torch launches
+                    if (isinstance(module, (nn.BatchNorm1d, nn.SyncBatchNorm)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                            and norm.fusable(module, input.features)):
+                        input = input.replace_feature(norm.bn_act(input.features, module, relu=True))
+                        i += 1
+                    else:
+                        input = input.replace_feature(module(input.features))
             else:
                 input = module(input)
+            i += 1
         return input
 
 

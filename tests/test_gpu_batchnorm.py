@@ -1,0 +1,155 @@
+"""Fused training-mode BatchNorm1d (+ residual) + ReLU (csrc/batchnorm.hip through the C ABI; spconv_backbone.py:21-25,52-64) against
+torch's own batch_norm / add / relu evaluated in float64 on the CPU: outputs, running statistics and every gradient.
+fp32: 1e-5 relative; bf16 / fp16: the storage rounding of y and dx (1e-2)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from openpcdet_amd.spconv import pytorch as spconv
+from openpcdet_amd.spconv.pytorch import norm
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def reference(x, res, bn, up, relu):
+    """float64 CPU: -> y, dx, dres, dgamma, dbeta, running_mean, running_var"""
+    xd = x.double().cpu().requires_grad_(True)
+    rd = res.double().cpu().requires_grad_(True) if res is not None else None
+    w = bn.weight.detach().double().cpu().requires_grad_(True)
+    b = bn.bias.detach().double().cpu().requires_grad_(True)
+    rm, rv = bn.running_mean.detach().double().cpu().clone(), bn.running_var.detach().double().cpu().clone()
+    y = F.batch_norm(xd, rm, rv, w, b, True, bn.momentum, bn.eps)
+    if rd is not None:
+        y = y + rd
+    if relu:
+        y = torch.relu(y)
+    (y * up.double().cpu()).sum().backward()
+    return y.detach(), xd.grad, (rd.grad if rd is not None else None), w.grad, b.grad, rm, rv
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("c", [16, 32, 64, 128])
+def test_bn_act_vs_torch(cuda_device, dtype, tol, c):
+    torch.manual_seed(c)
+    for n, with_res, relu in ((100003, True, True), (4097, False, True), (2, False, False)):
+        bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda_device).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(c) + 0.5)
+            bn.bias.copy_(torch.randn(c) * 0.2)
+            bn.running_mean.copy_(torch.randn(c) * 0.1)
+            bn.running_var.copy_(torch.rand(c) + 0.5)
+        x = (torch.randn(n, c, device=cuda_device) * 1.7 + 0.3).to(dtype)
+        res = torch.randn(n, c, device=cuda_device).to(dtype) if with_res else None
+        up = torch.randn(n, c, device=cuda_device).to(dtype)
+        want = reference(x, res, bn, up, relu)
+        xg = x.clone().requires_grad_(True)
+        rg = res.clone().requires_grad_(True) if with_res else None
+        assert norm.fusable(bn, xg)
+        y = norm.bn_act(xg, bn, residual=rg, relu=relu)
+        assert y.dtype == dtype and y.grad_fn is not None
+        (y.float() * up.float()).sum().backward()
+        assert rel_l2(y.detach().float().cpu(), want[0]) <= tol
+        assert rel_l2(xg.grad.float().cpu(), want[1]) <= max(tol, 1e-4) * (3 if n == 2 else 1)
+        if with_res:
+            assert rel_l2(rg.grad.float().cpu(), want[2]) <= tol
+        assert rel_l2(bn.weight.grad.cpu(), want[3]) <= max(tol, 1e-4) and rel_l2(bn.bias.grad.cpu(), want[4]) <= max(tol, 1e-4)
+        assert rel_l2(bn.running_mean.cpu(), want[5]) <= 1e-5 and rel_l2(bn.running_var.cpu(), want[6]) <= 1e-5
+        assert int(bn.num_batches_tracked) == 1
+
+
+def test_bn_act_fallbacks_and_sequential(cuda_device):
+    """eval mode, SyncBatchNorm-typed modules and unsupported widths go through the modules themselves; SparseSequential fuses the
+    BatchNorm1d -> ReLU pair in training mode and gives torch's result"""
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(24).to(cuda_device).train()
+    x = torch.randn(500, 24, device=cuda_device)
+    assert not norm.fusable(bn, x)                               # 24 fp32 channels = 6 chunks: does not tile a 256-thread workgroup
+    want = torch.relu(F.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.1, bn.eps))
+    assert torch.allclose(norm.bn_act(x, bn), want, atol=1e-6)
+    bn32 = torch.nn.BatchNorm1d(32).to(cuda_device)
+    x32 = torch.randn(500, 32, device=cuda_device)
+    assert norm.fusable(bn32.train(), x32) and not norm.fusable(bn32.eval(), x32) and not norm.fusable(bn32.train(), x32.cpu())
+    sync = torch.nn.SyncBatchNorm(32).to(cuda_device).train()
+    assert not norm.fusable(sync, x32)
+    # SparseSequential(conv, bn, relu): same features as conv -> torch bn -> relu
+    seq = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="k"), torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01),
+                                  torch.nn.ReLU()).to(cuda_device).train()
+    r = np.random.default_rng(1)
+    coords = np.unique(np.stack([np.zeros(3000, np.int64), r.integers(0, 8, 3000), r.integers(0, 30, 3000), r.integers(0, 30, 3000)], 1), axis=0)
+    feats = torch.randn(len(coords), 16, device=cuda_device, requires_grad=True)
+    xt = spconv.SparseConvTensor(feats, torch.from_numpy(coords.astype(np.int32)).to(cuda_device), [8, 30, 30], 1)
+    out = seq(xt)
+    conv_out = seq[0](xt).features
+    want = torch.relu(F.batch_norm(conv_out, None, None, seq[1].weight, seq[1].bias, True, 0.01, 1e-3))
+    assert rel_l2(out.features.detach().cpu(), want.detach().cpu()) <= 1e-5
+    out.features.square().mean().backward()
+    assert feats.grad is not None and seq[1].weight.grad is not None and float(seq[0].weight.grad.abs().sum()) > 0
+    assert int(seq[1].num_batches_tracked) == 1                   # the explicit seq[0](xt) call above does not touch the BatchNorm
+
+
+def _sync_worker(rank, world, port, out):
+    """one of two ranks on the same GPU (gloo carries the CUDA tensors of the all-reduce): each normalises its half of the rows with
+    statistics over both halves"""
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(11)
+        c, n = 32, 9001
+        x = (torch.randn(n, c) * 1.3 + 0.4).to(dev)
+        res = torch.randn(n, c).to(dev)
+        up = torch.randn(n, c).to(dev)
+        lo, hi = (0, 5000) if rank == 0 else (5000, n)          # unequal shares
+        bn = torch.nn.SyncBatchNorm(c, eps=1e-3, momentum=0.01).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+            bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+        xs = x[lo:hi].clone().requires_grad_(True)
+        rs = res[lo:hi].clone().requires_grad_(True)
+        assert norm.fusable(bn, xs)
+        y = norm.bn_act(xs, bn, residual=rs, relu=True)
+        (y * up[lo:hi]).sum().backward()
+        out[rank] = dict(y=y.detach().cpu(), dx=xs.grad.cpu(), dres=rs.grad.cpu(), dw=bn.weight.grad.cpu(), db=bn.bias.grad.cpu(),
+                         rm=bn.running_mean.cpu(), rv=bn.running_var.cpu())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks(cuda_device):
+    """SyncBatchNorm through the fused kernels at world size 2 == BatchNorm over the concatenated rows (float64 CPU reference);
+    weight / bias gradients are per-rank sums whose total is the reference's"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sync_worker, args=(2, port, out), nprocs=2, join=True)
+    torch.manual_seed(11)
+    c, n = 32, 9001
+    x = torch.randn(n, c) * 1.3 + 0.4
+    res = torch.randn(n, c)
+    up = torch.randn(n, c)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, c))
+        bn.bias.copy_(torch.linspace(-0.3, 0.3, c))
+    want = reference(x, res, bn, up, True)
+    y = torch.cat([out[0]["y"], out[1]["y"]])
+    dx = torch.cat([out[0]["dx"], out[1]["dx"]])
+    dres = torch.cat([out[0]["dres"], out[1]["dres"]])
+    assert rel_l2(y, want[0]) <= 1e-5 and rel_l2(dx, want[1]) <= 1e-4 and rel_l2(dres, want[2]) <= 1e-5
+    assert rel_l2(out[0]["dw"] + out[1]["dw"], want[3]) <= 1e-4 and rel_l2(out[0]["db"] + out[1]["db"], want[4]) <= 1e-4
+    for r in (0, 1):
+        assert rel_l2(out[r]["rm"], want[5]) <= 1e-5 and rel_l2(out[r]["rv"], want[6]) <= 1e-5

@@ -180,17 +180,16 @@ def test_training_step_backbone_grads(cuda_device):
         coords.append(np.concatenate([np.full((len(czyx), 1), b, np.int32), czyx], 1))
     x, c = np.concatenate(feats), np.concatenate(coords)
     xr = torch.from_numpy(x)
-    # reference first (CPU, fp32)
-    n_out = None
-    loss_ref, out_ref = _ref_backbone_loss(net, xr, c, net.sparse_shape, 2, 1.0)
+    # reference first: CPU autograd in float64 over a copy of the module, so that the checker adds no rounding of its own (21 layers of
+    # batch-statistic BatchNorm amplify fp32 rounding to ~2e-3 on some gradients, which is the bar below)
+    import copy
+    net64 = copy.deepcopy(net).double()
+    _, out_ref = _ref_backbone_loss(net64, xr.double(), c, net.sparse_shape, 2, 1.0)
     up = torch.from_numpy(np.random.default_rng(3).normal(size=tuple(out_ref.shape)).astype(np.float32))
-    for p in net.parameters():
-        p.grad = None
-    loss_ref, out_ref = _ref_backbone_loss(net, xr, c, net.sparse_shape, 2, up)
+    loss_ref, out_ref = _ref_backbone_loss(net64, xr.double(), c, net.sparse_shape, 2, up.double())
     loss_ref.backward()
-    want = {k: p.grad.clone() for k, p in net.named_parameters()}
-    for p in net.parameters():
-        p.grad = None
+    want = {k: p.grad.float().clone() for k, p in net64.named_parameters()}
+    out_ref = out_ref.float()
     # device
     net = net.to(cuda_device)
     bd = net({"voxel_features": xr.to(cuda_device), "voxel_coords": torch.from_numpy(c).to(cuda_device), "batch_size": 2})
@@ -296,8 +295,11 @@ def test_grads_flow_through_dense_scatter_and_bev_out(cuda_device):
 
 def test_ddp_syncbn_world1_training_step(cuda_device):
     """tools/train.py:130-131,162: the module API under SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel over RCCL
-    (world size 1 here; the world-size-2 gradient average is tests/test_dist_gloo.py): a bf16 autocast step through
-    VoxelResBackBone8x -> HeightCompression yields the same loss and parameter gradients as the unwrapped module."""
+    (world size 1 here; the world-size-2 gradient average is tests/test_dist_gloo.py): an fp32 step through VoxelResBackBone8x ->
+    HeightCompression yields the same loss and parameter gradients as the unwrapped module (whose BatchNorm1d + ReLU pairs run in the
+    fused kernels of csrc/batchnorm.hip, while SyncBatchNorm runs torch's); a bf16 autocast step of the wrapped module then runs and
+    gives finite gradients (bf16 gradients of the first layers differ by tens of per cent between ANY two roundings of this 21-layer
+    batch-statistic network, see test_training_step_backbone_grads, so they are not compared here)."""
     import copy
     import torch.distributed as dist
     from openpcdet_amd import voxelize
@@ -315,10 +317,10 @@ def test_ddp_syncbn_world1_training_step(cuda_device):
     feats, coords = torch.cat(feats), torch.cat(coords)
     hc = backbones.HeightCompression()
 
-    def run(model):
+    def run(model, autocast=False):
         for p in model.parameters():
             p.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
             bev = hc(model({"voxel_features": feats, "voxel_coords": coords, "batch_size": 2}))["spatial_features"]
             loss = (bev.float() ** 2).mean()
         loss.backward()
@@ -338,11 +340,14 @@ def test_ddp_syncbn_world1_training_step(cuda_device):
         loss1 = run(ddp)
         got = {k: p.grad for k, p in wrapped.named_parameters()}
         assert set(got) == set(want)
-        assert abs(loss1 - loss0) <= 2e-2 * abs(loss0), (loss0, loss1)
+        assert abs(loss1 - loss0) <= 1e-4 * abs(loss0), (loss0, loss1)
         for k in want:
             assert got[k] is not None, k
             if not k.endswith(("conv1.bias", "conv2.bias")):      # zero-gradient biases ahead of BatchNorm: rounding noise only
-                assert rel_l2(got[k].float().cpu().numpy(), want[k].float().cpu().numpy()) <= 5e-2, k
+                assert rel_l2(got[k].float().cpu().numpy(), want[k].float().cpu().numpy()) <= 1e-2, k
+        loss2 = run(ddp, autocast=True)
+        assert abs(loss2 - loss0) <= 2e-2 * abs(loss0), (loss0, loss2)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in wrapped.parameters())
         torch.optim.AdamW(wrapped.parameters(), lr=1e-3).step()
     finally:
         if created:
