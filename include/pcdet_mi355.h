@@ -473,6 +473,38 @@ int pvx_bn_act_bwd_sync(const void* dy, const void* x, const void* y, int n, int
                         float* dbeta, double* sums, long long n_total, int phase, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Point-level preparation ahead of the voxelizer: the world augmentations and the range mask /
+ * shuffle the reference runs with numpy in DataLoader workers.  binary32 arithmetic in the reference's order (numpy 1.x casting:
+ * the drawn float64 scalars act as float32), no contraction.
+ * ---------------------------------------------------------------------------------------------------- */
+enum {
+    PVX_AUG_FLIP_X = 0,     /* random_flip_along_x, augmentor_utils.py:8-26: y -> -y, heading -> -heading, vy -> -vy */
+    PVX_AUG_FLIP_Y = 1,     /* random_flip_along_y, :29-47: x -> -x, heading -> -(heading + pi), vx -> -vx */
+    PVX_AUG_ROTATE = 2,     /* global_rotation, :50-71: a = cos, b = sin, c = angle (about z, x towards y) */
+    PVX_AUG_SCALE = 3,      /* global_scaling, :74-91: a = scale */
+    PVX_AUG_TRANSLATE = 4,  /* random_world_translation, data_augmentor.py:140-161: (a, b, c) added to xyz */
+    PVX_AUG_LIMIT_HEADING = 5 /* boxes only, data_augmentor.py:309-311: heading -= floor(heading / a + b) * a (a = period) */
+};
+typedef struct { int kind; float a, b, c; } pvx_point_op;
+#define PVX_AUG_MAX_OPS 16
+
+/* Apply n_ops (HOST array, <= PVX_AUG_MAX_OPS) operations, in order, in place: to columns 0..2 of points [n, c] (c >= 3), or to
+ * boxes [n, c] = (x, y, z, dx, dy, dz, heading[, vx, vy, ...]) with c == 7 or c >= 9 (columns >= 7 only scale). */
+int pvx_points_transform(float* points, int n, int c, const pvx_point_op* ops, int n_ops, void* stream);
+int pvx_boxes_transform(float* boxes, int n, int c, const pvx_point_op* ops, int n_ops, void* stream);
+
+/* mask_points_and_boxes_outside_range + shuffle_points (data_processor.py:81-112) for the points of one frame: out receives the
+ * rows points[perm[i]] (perm: device int64 permutation of 0..n-1; NULL = the keyed bijection of [0, n) that shuffle_seed selects
+ * -- a 6-round Feistel network with cycle walking, computed in the kernel, for a shuffle without a permutation array or a sort
+ * (the reference draws np.random.permutation, :107-110) -- or, with shuffle_seed == 0, the identity) that pass x0 <= x <= x1 && y0 <= y <= y1
+ * (range_xy: HOST {x0, y0, x1, y1}, NULL = keep all; common_utils.py:78-81), in order of i; *count (device) = rows written.  A
+ * uniform permutation followed by this stable compaction orders the kept rows uniformly at random, which is what shuffling after
+ * the mask does.  out must not alias points; out has room for n rows. */
+size_t pvx_points_prepare_workspace_bytes(int n);
+int pvx_points_prepare(const float* points, int n, int c, const int64_t* perm, uint64_t shuffle_seed, const float* range_xy,
+                       float* out, int* count, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,11 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_void_p, c_size_t, c_void_p]),
     "pvx_bn_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_points_transform": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "pvx_boxes_transform": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "pvx_points_prepare_workspace_bytes": (c_size_t, [c_int]),
+    "pvx_points_prepare": (c_int, [c_void_p, c_int, c_int, c_void_p, ctypes.c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
     "pvx_nms_static": (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "pvx_boxes_iou_bev_cpu": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "pvx_boxes_aligned_iou_bev_cpu": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),

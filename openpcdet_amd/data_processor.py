@@ -5,16 +5,42 @@ the padded voxel tensors are pickled to the training process (32 MB per frame). 
 `DataProcessorGPU(processor_configs, point_cloud_range, training, num_point_features)` takes the same config list (dicts or
 EasyDicts with NAME, and per step REMOVE_OUTSIDE_BOXES / SHUFFLE_ENABLED / VOXEL_SIZE / MAX_POINTS_PER_VOXEL /
 MAX_NUMBER_OF_VOXELS) and `forward(data_dict)` rewrites `points` and adds `voxels`, `voxel_coords`, `voxel_num_points` as device
-tensors.  Steps without a point-level meaning here (gt box filtering beyond the centre test, image steps) are passed through to an
-optional CPU fallback processor."""
+tensors.  The mask and the shuffle are one HIP pass (`pvx_points_prepare`, csrc/point_prep.hip: gather by a permutation + stable
+compaction); the world augmentations that precede them in the reference's `prepare_data` are in data_augmentor.py.  Steps without
+a point-level meaning here (image steps, corner-count box filtering) raise NotImplementedError."""
+import ctypes
+
 import numpy as np
 import torch
 
-from . import voxelize
+from . import _lib, voxelize
 
 
 def _get(cfg, name, default=None):
     return cfg.get(name, default) if isinstance(cfg, dict) else getattr(cfg, name, default)
+
+
+def prepare_points(points, perm=None, range_xy=None, shuffle_seed=0):
+    """rows points[perm] (perm: int64 device permutation; None = the keyed bijection `shuffle_seed` selects, computed in the kernel,
+    or the identity for seed 0) inside x0 <= x <= x1, y0 <= y <= y1 (range_xy, None =
+    all), in order: `pvx_points_prepare`, one gather + stable compaction for mask_points_by_range (common_utils.py:78-81) and
+    shuffle_points (data_processor.py:104-112).  One host read of the count, as `points[mask]` has."""
+    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    n, c = points.shape
+    if perm is not None:
+        assert perm.dtype == torch.int64 and perm.is_cuda and perm.is_contiguous() and perm.numel() == n
+    L = _lib.lib()
+    out = torch.empty_like(points)
+    count = torch.empty(1, dtype=torch.int32, device=points.device)
+    ws_bytes = L.pvx_points_prepare_workspace_bytes(n)
+    ws = _lib.workspace(ws_bytes, points.device)
+    rng = (ctypes.c_float * 4)(*[float(v) for v in range_xy]) if range_xy is not None else None
+    with torch.cuda.device(points.device):
+        _lib.check(L.pvx_points_prepare(_lib.ptr(points), n, c, _lib.ptr(perm), int(shuffle_seed) & (2 ** 64 - 1), rng, _lib.ptr(out), _lib.ptr(count), _lib.ptr(ws),
+                                        ws_bytes, _lib.stream()), "pvx_points_prepare")
+    if range_xy is None:
+        return out                                     # nothing dropped: no host read
+    return out[:int(count.item())]
 
 
 class DataProcessorGPU:
@@ -40,13 +66,23 @@ class DataProcessorGPU:
                 self.grid_size = np.round(g).astype(np.int64)
                 self.voxel_size = vs
 
+    def _shuffle_args(self, n):
+        """how to shuffle n rows: with a torch generator, a drawn permutation (torch.randperm: random keys + a device sort,
+        160 us for 300k rows); without, a seed drawn from numpy's global generator -- the one the reference's
+        np.random.permutation (data_processor.py:107-110) uses -- for the kernel's own keyed bijection (no array, no sort)"""
+        if self.generator is not None:
+            return dict(perm=torch.randperm(n, device=self.device, generator=self.generator))
+        return dict(shuffle_seed=int(np.random.randint(1, 2 ** 63 - 1, dtype=np.int64)))
+
     # data_processor.py:81-102
-    def mask_points_and_boxes_outside_range(self, data_dict, config):
+    def mask_points_and_boxes_outside_range(self, data_dict, config, shuffle=False):
+        """shuffle=True folds the shuffle_points step that follows into the same pass: a uniform permutation of ALL rows followed
+        by the order-keeping mask leaves the kept rows in uniformly random order, which is what shuffling after the mask does"""
         pts = data_dict.get('points')
         if pts is not None:
             r = self.point_cloud_range
-            mask = (pts[:, 0] >= float(r[0])) & (pts[:, 0] <= float(r[3])) & (pts[:, 1] >= float(r[1])) & (pts[:, 1] <= float(r[4]))
-            data_dict['points'] = pts[mask]
+            data_dict['points'] = prepare_points(pts, range_xy=(r[0], r[1], r[3], r[4]),
+                                                  **(self._shuffle_args(pts.shape[0]) if shuffle else {}))
         boxes = data_dict.get('gt_boxes')
         if boxes is not None and _get(config, 'REMOVE_OUTSIDE_BOXES', False) and self.training:
             if not _get(config, 'USE_CENTER_TO_FILTER', True):
@@ -63,7 +99,7 @@ class DataProcessorGPU:
         enabled = _get(config, 'SHUFFLE_ENABLED')
         if enabled[self.mode]:
             pts = data_dict['points']
-            data_dict['points'] = pts[torch.randperm(pts.shape[0], device=pts.device, generator=self.generator)]
+            data_dict['points'] = prepare_points(pts, **self._shuffle_args(pts.shape[0]))
         return data_dict
 
     # data_processor.py:114-122
@@ -109,6 +145,18 @@ class DataProcessorGPU:
         pts = data_dict.get('points')
         if pts is not None and not torch.is_tensor(pts):
             data_dict['points'] = torch.from_numpy(np.ascontiguousarray(pts, np.float32)).to(self.device)
-        for step, cfg in self.queue:
+        elif pts is not None:
+            data_dict['points'] = pts.to(self.device, torch.float32).contiguous()
+        q = self.queue
+        i = 0
+        while i < len(q):
+            step, cfg = q[i]
+            nxt = q[i + 1] if i + 1 < len(q) else None
+            if (step == self.mask_points_and_boxes_outside_range and nxt is not None and nxt[0] == self.shuffle_points
+                    and _get(nxt[1], 'SHUFFLE_ENABLED')[self.mode]):
+                data_dict = step(data_dict, cfg, shuffle=True)       # mask + shuffle: one gather / compaction pass
+                i += 2
+                continue
             data_dict = step(data_dict, cfg)
+            i += 1
         return data_dict
