@@ -108,18 +108,33 @@ class SparseConvolution(SparseModule):
                 self.bias.uniform_(-b, b)
 
     # ---- weights in kernel order ---------------------------------------------------------------------------
+    def _padded_cin(self, dtype):
+        """input channels the forward kernel is given: a narrow first layer (the 4- or 5-channel voxel means) is zero-padded to
+        16 channels when that puts it on the MFMA kernels instead of the scalar one (the products with the padding are zeros)"""
+        cin = self.in_channels
+        if cin < 16 and dtype != torch.float32:
+            L = _lib.lib()
+            code = _lib.DTYPE_CODE[dtype]
+            if not L.pvx_sparse_conv_uses_mfma(cin, self.out_channels, code) and L.pvx_sparse_conv_uses_mfma(16, self.out_channels, code):
+                return 16
+        return cin
+
     def _prepared_weight(self, weight, dtype):
         key = (weight.data_ptr(), weight._version, weight.dtype, dtype, weight.device)
         if self._prepared is not None and self._prepared[0] == key:
             return self._prepared[1]
         L = _lib.lib()
-        w = weight.detach().to(dtype).contiguous()
+        w = weight.detach().to(dtype)
+        cin = self._padded_cin(dtype)
+        if cin != self.in_channels:
+            w = torch.nn.functional.pad(w, (0, cin - self.in_channels))
+        w = w.contiguous()
         kvol = int(np.prod(self.kernel_size))
         code = _lib.DTYPE_CODE[dtype]
-        nbytes = L.pvx_sparse_conv_weight_bytes(self.out_channels, kvol, self.in_channels, code)
+        nbytes = L.pvx_sparse_conv_weight_bytes(self.out_channels, kvol, cin, code)
         out = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         with torch.cuda.device(weight.device):
-            _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), self.out_channels, kvol, self.in_channels, code,
+            _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), self.out_channels, kvol, cin, code,
                                                         _lib.ptr(out), _lib.stream()), "pvx_sparse_conv_prepare_weight")
         self._prepared = (key, out)
         return out
@@ -130,10 +145,13 @@ class SparseConvolution(SparseModule):
         dtype = features.dtype
         kvol = int(np.prod(self.kernel_size))
         pw = self._prepared_weight(weight, dtype)
+        cin = self._padded_cin(dtype)
+        if cin != self.in_channels:
+            features = torch.nn.functional.pad(features, (0, cin - self.in_channels))
         b32 = bias.detach().float().contiguous() if bias is not None else None
         out = torch.empty((n_out, self.out_channels), dtype=dtype, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.pvx_sparse_conv_fwd(_lib.ptr(features), features.shape[0], self.in_channels, _lib.ptr(pw),
+            _lib.check(L.pvx_sparse_conv_fwd(_lib.ptr(features), features.shape[0], cin, _lib.ptr(pw),
                                              _lib.ptr(b32), _lib.ptr(nbr), kvol, n_out, None, self.out_channels,
                                              _lib.DTYPE_CODE[dtype], None, None, None, 0, _lib.ptr(out), _lib.stream()),
                        "pvx_sparse_conv_fwd")
