@@ -103,7 +103,10 @@ def conv_kernel_name(cin, cout, kvol):
     if os.environ.get("PVX_CONV_V3", "0") != "0" and kvol == 27 and (cin, cout) in ((64, 64), (128, 128), (64, 128)):
         return "sparse_conv_v3_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in engine.HotPathEngine.TILEBOOK_SHAPES and os.environ.get("PVX_ENGINE_TILEBOOK", "1") == "1":
-        return "sparse_conv_slab_tb_kernel<bf16,%d,%d>" % (cin, cout)
+        if (cin, cout) == (32, 32) and os.environ.get("PVX_CONV_ROLL", "1") != "0":
+            return "sparse_conv_slab_roll_kernel<bf16,%d,%d>" % (cin, cout)
+        if (cin, cout) == (16, 16):
+            return "sparse_conv_slab_tb_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in ((16, 16), (16, 32), (32, 32), (32, 64), (64, 64)):
         return "sparse_conv_slab_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in ((64, 128), (128, 64), (128, 128)):

@@ -126,12 +126,18 @@ class HotPathEngine:
         with torch.cuda.device(dev):
             self._build(backbone, level_capacity_factor)
 
-    TILEBOOK_SHAPES = {(16, 16)}
+    # layers that share a rulebook with enough launches to pay for its book (55 us): the five 16 -> 16 layers (bound by rulebook
+    # bytes) and the four 32 -> 32 layers (the rolling kernel form needs the book's window spans a tile ahead)
+    TILEBOOK_SHAPES = {(16, 16), (32, 32)}
 
     def _wants_tilebook(self, cin, cout):
         if self.tilebook_mode == "0":
             return False
-        return self.tilebook_mode == "all" or (cin, cout) in self.TILEBOOK_SHAPES
+        if self.tilebook_mode == "all":
+            return True
+        if (cin, cout) == (32, 32):                    # only for the rolling kernel form (its books have 896-row windows)
+            return _lib.lib().pvx_tilebook_rcap(32, 32, 27, self.code) >= 896
+        return (cin, cout) in self.TILEBOOK_SHAPES
 
     # ------------------------------------------------------------------------------------------------------------
     def _feat_buf(self, level, channels, avoid=()):
