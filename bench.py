@@ -122,9 +122,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--no-vox-ahead", action="store_true",
                     help="voxelize each batch inside its own step instead of one step ahead, beside the previous batch's rulebooks")
-    ap.add_argument("--geo-after", type=int, default=9,
-                    help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 8..11 measured "
-                         "best for this backbone with the in-kernel NMS front end: profiles/r02_schedule_sweep.txt)")
+    ap.add_argument("--geo-after", type=int, default=6,
+                    help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 6..7 measured "
+                         "best for this backbone with the in-kernel NMS front end and the rolling 32->32 kernel: profiles/r02_schedule_sweep.txt)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
     ap.add_argument("--nms-stream", default="own", choices=("own", "vox"), help="stream of the NMS launches: its own, or the voxelizer's")
