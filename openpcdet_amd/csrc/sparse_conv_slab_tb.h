@@ -442,7 +442,8 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_roll_kernel(const E* 
                 }
 #ifndef PVX_SLAB_ABL_NOFALLBACK
                 if (!all_in && __ballot(code == kTbFar) != 0ull) {           // wave-uniform: somebody's neighbour is outside the window
-                    // (requesting the nine full indices of a group together, ahead of the offset loop, measured SLOWER: 296 vs 268 us)
+                    // (requesting the nine full indices of a group together, ahead of the offset loop, measured SLOWER, 296 vs 268 us, and so did
+                    // letting the next offset's index ride with this offset's gathers, 339 vs 270 us: r02_roll_kernel.txt)
                     int r = -1;
                     if (code == kTbFar) r = nbr[(size_t)(g * GK + kk_) * n_out + site];   // a far code exists only for live sites
                     const unsigned voff = (r >= 0 && r < n_in) ? (unsigned)r * (unsigned)(CIN * sizeof(E)) + (unsigned)(half * 16) : feat_bytes;
