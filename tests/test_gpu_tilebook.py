@@ -136,3 +136,34 @@ def test_tilebook_strided_rulebook_and_empty(cuda_device):
         assert torch.equal(got, want), live
     assert L.pvx_tilebook_rcap(128, 128, 27, 2) == 0 and L.pvx_tilebook_rcap(16, 16, 27, 0) == 0 and L.pvx_tilebook_rcap(16, 16, 9, 2) == 0
     assert L.pvx_tilebook_build(None, 9, 10, None, 10, 100, None, None) == -1
+
+
+def test_rolling_form_small_counts_and_long_lines(cuda_device):
+    """the 32 -> 32 rolling kernel (its own 896-row window): device-side live counts around the tile size (a workgroup with one
+    tile, XCDs without tiles, no next tile to prefetch), and a grid whose y-lines are longer than the window holds, so that
+    rows in key order still leave neighbours outside it (the far path beside the register prefetch)"""
+    L = _lib.lib()
+    dev = cuda_device
+    rcap = L.pvx_tilebook_rcap(32, 32, 27, 2)
+    assert rcap == 896
+    r = np.random.default_rng(4)
+    shape = [3, 24, 1500]
+    coords = sites(77, 1, shape, 70000, True)                 # ~65 % occupancy: ~1000 sites per y-line
+    n = len(coords)
+    nbr = loader.subm_rulebook(coords, shape, (3, 3, 3))
+    nbr_t = torch.from_numpy(np.ascontiguousarray(nbr)).to(dev)
+    feat = torch.from_numpy(r.normal(size=(n, 32)).astype(np.float32)).to(dev).bfloat16()
+    w = torch.from_numpy((r.normal(size=(32, 27, 32)) / 30).astype(np.float32)).to(dev).bfloat16()
+    res = torch.from_numpy(r.normal(size=(n, 32)).astype(np.float32)).to(dev).bfloat16()
+    for live in (n, 0, 1, 255, 256, 257, 600, 256 * 9 + 3):
+        n_live = torch.tensor([live], dtype=torch.int32, device=dev)
+        book = torch.zeros(L.pvx_tilebook_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, n, _lib.ptr(n_live), n, rcap, _lib.ptr(book), _lib.stream()), "build")
+        if live == n:
+            _, ent = book_numpy(nbr, n, n, rcap)
+            far = (ent == 0xFFFE).mean()
+            assert 0.001 < far < 0.5, far                     # key order, and still neighbours beyond 896 rows
+        for rr in (None, res):
+            want, _ = run_conv(dev, feat, w, nbr_t, n_live, 32, 32, 2, residual=rr)
+            got, _ = run_conv(dev, feat, w, nbr_t, n_live, 32, 32, 2, book=book, rcap=rcap, residual=rr)
+            assert torch.equal(got, want), (live, rr is None)
