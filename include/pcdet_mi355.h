@@ -341,6 +341,10 @@ int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prep
 int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype);
 size_t pvx_tilebook_bytes(int n_out);
 int pvx_tilebook_build(const int* nbr, int kvol, int n_out, const int* n_out_dev, int n_in, int rcap, void* book, void* stream);
+/* pvx_subm_rulebook for a 3 x 3 x 3 kernel and pvx_tilebook_build of its rulebook (n_in = n) in ONE pass: the 27 entries of a
+ * tile's sites are in registers when the rulebook is written, so the book costs its stores only.  Same nbr, same book. */
+int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                         const int* perm, const int* dilation, int* nbr, int rcap, void* book, void* stream);
 int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
                            const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
                            const float* scale, const float* shift, const void* residual, int relu, void* out,

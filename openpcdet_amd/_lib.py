@@ -98,6 +98,8 @@ SIGNATURES = {
                                      c_size_t, c_void_p]),
     "pvx_subm_rulebook": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "pvx_subm_rulebook_tb": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_void_p]),
     "pvx_conv_out_shape": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pvx_conv_out_index": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -16,6 +16,7 @@
 // the implicit-GEMM kernels in sparse_conv.hip consume.
 #include "pvx_common.h"
 #include "scan_util.h"
+#include "tilebook_layout.h"
 
 namespace {
 
@@ -145,6 +146,42 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restri
             }
         }
     }
+}
+
+// The same for a 3 x 3 x 3 kernel, plus the rulebook's TILE BOOK (tilebook_layout.h) in the same pass: the workgroup's 256 sites are
+// exactly one tile and their 27 entries are in registers already, so the book costs its 13.5 KiB of stores per tile instead of a
+// second kernel that reads the 27-KiB rulebook slice back (pvx_tilebook_build).  Same rulebook, same book, bit for bit.
+__global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __restrict__ coords, int n,
+                                                                 const int* __restrict__ n_dev, Dims s,
+                                                                 const IndexEntry* __restrict__ idx,
+                                                                 const int* __restrict__ perm, int dd, int dh, int dw,
+                                                                 int* __restrict__ nbr, int rcap, uint4* __restrict__ book) {
+    static_assert(kBlk == kTbTile, "one workgroup = one tile");
+    __shared__ int g_lo[3], g_hi[3];
+    const int n_live = live_rows(n, n_dev);
+    if ((int)blockIdx.x * kBlk >= n_live) return;              // the whole workgroup: no tile, no book block
+    const int o = blockIdx.x * kBlk + threadIdx.x;
+    int v[kTbK];
+#pragma unroll
+    for (int k = 0; k < kTbK; k++) v[k] = -1;
+    if (o < n_live) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[o];
+        long long cword = -1;
+        uint4 craw = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < kTbK; k++) {
+            const int z = c.y + (k / 9 - 1) * dd, y = c.z + ((k / 3) % 3 - 1) * dh, x = c.w + (k % 3 - 1) * dw;
+            if (z >= 0 && z < s.d && y >= 0 && y < s.h && x >= 0 && x < s.w && c.x >= 0 && c.x < s.b) {
+                const int r = rank_of_cached(idx, lin_key(c.x, z, y, x, s), cword, craw);
+                if (r >= 0) v[k] = perm ? perm[r] : r;
+            }
+            nbr[(size_t)k * n + o] = v[k];
+        }
+    }
+    int vb[kTbK];
+#pragma unroll
+    for (int k = 0; k < kTbK; k++) vb[k] = v[k] >= n ? -1 : v[k];    // as pvx_tilebook_build with n_in = n
+    tilebook_emit(vb, threadIdx.x, rcap, book + (size_t)blockIdx.x * kTbU4, g_lo, g_hi);
 }
 
 // Strided conv, phase 1: mark every output cell reached by some (input site, offset).
@@ -372,6 +409,22 @@ extern "C" int pvx_subm_rulebook(const int* coords, int n, const int* n_dev, int
     for (int j = 0; j < 3; j++) if (ksize[j] <= 0 || (ksize[j] & 1) == 0 || dilation[j] <= 0) return PVX_ERR_INVALID;
     hipLaunchKernelGGL(subm_rulebook_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
                        (const IndexEntry*)index, perm, ksize[0], ksize[1], ksize[2], dilation[0], dilation[1], dilation[2], nbr);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+extern "C" int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                    const void* index, const int* perm, const int* dilation, int* nbr, int rcap, void* book,
+                                    void* stream) {
+    if (n < 0 || !shape_dhw || !dilation || rcap <= 0 || rcap >= (int)kTbFar) return PVX_ERR_INVALID;
+    if (n == 0) return PVX_OK;
+    if (!coords || !index || !nbr || !book) return PVX_ERR_INVALID;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    for (int j = 0; j < 3; j++) if (dilation[j] <= 0) return PVX_ERR_INVALID;
+    hipLaunchKernelGGL(subm_rulebook_tb_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
+                       (const IndexEntry*)index, perm, dilation[0], dilation[1], dilation[2], nbr, rcap, (uint4*)book);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

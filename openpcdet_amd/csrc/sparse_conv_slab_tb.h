@@ -12,67 +12,26 @@
 // the other half of a double buffer by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write) while this tile computes.
 #pragma once
 
-constexpr int kTbTile = 256, kTbK = 27;
-constexpr int kTbU4 = 2 + kTbK * kTbTile * 2 / 16;             // 866 uint4 per tile
-constexpr unsigned kTbNone = 0xFFFFu, kTbFar = 0xFFFEu;
+#include "tilebook_layout.h"
 
 // one workgroup per tile, thread = site
 __global__ __launch_bounds__(kTbTile) void tilebook_kernel(const int* __restrict__ nbr, int n_out, const int* __restrict__ n_out_dev,
                                                             int n_in, int rcap, uint4* __restrict__ book) {
     __shared__ int g_lo[3], g_hi[3];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int n_live = live_rows(n_out, n_out_dev);
     const int tile = blockIdx.x;
     if (tile * kTbTile >= n_live) return;
     const int site = tile * kTbTile + tid;
-    if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
-    __syncthreads();
     int v[kTbK];
-    int lo[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff }, hi[3] = { -1, -1, -1 };
 #pragma unroll
     for (int k = 0; k < kTbK; k++) {
         int r = -1;
         if (site < n_live) r = nbr[(size_t)k * n_out + site];
         if (r >= n_in) r = -1;
         v[k] = r;
-        if (r >= 0) { lo[k / 9] = min(lo[k / 9], r); hi[k / 9] = max(hi[k / 9], r); }
     }
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-        int l = lo[g], h = hi[g];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { l = min(l, __shfl_xor(l, off)); h = max(h, __shfl_xor(h, off)); }
-        if (lane == 0 && h >= 0) { atomicMin(&g_lo[g], l); atomicMax(&g_hi[g], h); }
-    }
-    __syncthreads();
-    int wlo[3], cnt[3];
-    unsigned flags = 0;
-#pragma unroll
-    for (int g = 0; g < 3; g++) {                              // the window rule of sparse_conv_slab_kernel
-        wlo[g] = 0; cnt[g] = 0;
-        if (g_hi[g] >= 0) {
-            const int span = g_hi[g] - g_lo[g] + 1;
-            cnt[g] = span <= rcap ? span : rcap;
-            wlo[g] = span <= rcap ? g_lo[g] : g_lo[g] + (span - rcap) / 2;
-            flags |= 1u << g;
-            if (span <= rcap) flags |= 16u << g;
-        }
-    }
-    uint4* blk = book + (size_t)tile * kTbU4;
-    if (tid == 0) {
-        blk[0] = make_uint4((unsigned)wlo[0], (unsigned)cnt[0], (unsigned)wlo[1], (unsigned)cnt[1]);
-        blk[1] = make_uint4((unsigned)wlo[2], (unsigned)cnt[2], flags, 0u);
-    }
-    unsigned short* ent = reinterpret_cast<unsigned short*>(blk + 2);
-#pragma unroll
-    for (int k = 0; k < kTbK; k++) {
-        unsigned code = kTbNone;
-        if (v[k] >= 0) {
-            const int local = v[k] - wlo[k / 9];
-            code = (local >= 0 && local < cnt[k / 9]) ? (unsigned)local : kTbFar;
-        }
-        ent[k * kTbTile + tid] = (unsigned short)code;
-    }
+    tilebook_emit(v, tid, rcap, book + (size_t)tile * kTbU4, g_lo, g_hi);
 }
 
 template <typename E, int CIN, int COUT, int RCAP, int WGS>

@@ -196,6 +196,7 @@ class HotPathEngine:
 
         self.ops = []          # (name, callable(stream))
         self._books = {}       # (rulebook address, window rows) -> tile book buffer
+        self._subm_ops = {}    # rulebook address -> (index in self.ops, arguments) of the launch that builds it, while it has no book
         # which (cin, cout) layers read their rulebook through a tile book: building one costs about as much as one 16 -> 16
         # layer saves, so it pays where several rulebook-bound layers share it -- the five 16 -> 16 layers of level 0 (104 -> 68 us
         # each at B = 16); 32 -> 32 and 64 -> 64 gain 0-3 %, less than their book costs (profiles/r02_tilebook.txt).
@@ -219,6 +220,8 @@ class HotPathEngine:
             args = (_lib.ptr(level.coords), level.cap, _lib.ptr(level.n_dev), B, level.c_shape, _lib.ptr(level.index),
                     _lib.ptr(level.perm), k3, d3, _lib.ptr(nbr))
             self.ops.append(("subm_rulebook", lambda st, a=args: _lib.check(L.pvx_subm_rulebook(*a, st), "pvx_subm_rulebook")))
+            if tuple(conv.kernel_size) == (3, 3, 3):       # a tile book wanted later is written by this very launch (add_conv)
+                self._subm_ops[nbr.data_ptr()] = (len(self.ops) - 1, args)
             return nbr
 
         def add_conv(spec, level_in, level_out, feat_in, cin, nbr, residual_buf, avoid):
@@ -240,8 +243,15 @@ class HotPathEngine:
                 if book is None:
                     book = torch.empty(L.pvx_tilebook_bytes(level_out.cap), dtype=torch.uint8, device=dev)
                     self._books[bkey] = book
-                    ab = (_lib.ptr(nbr), kvol, level_out.cap, _lib.ptr(level_out.n_dev), level_in.cap, rcap, _lib.ptr(book))
-                    self.ops.append(("tilebook", lambda st, a=ab: _lib.check(L.pvx_tilebook_build(*a, st), "pvx_tilebook_build")))
+                    fuse = self._subm_ops.pop(nbr.data_ptr(), None) if os.environ.get("PVX_ENGINE_FUSED_BOOK", "1") != "0" else None
+                    if fuse is not None:
+                        # the submanifold rulebook's own launch writes the book too (pvx_subm_rulebook_tb): no second pass over nbr
+                        at, ra = fuse
+                        af = ra[:7] + (ra[8], ra[9], rcap, _lib.ptr(book))
+                        self.ops[at] = ("subm_rulebook", lambda st, a=af: _lib.check(L.pvx_subm_rulebook_tb(*a, st), "pvx_subm_rulebook_tb"))
+                    else:
+                        ab = (_lib.ptr(nbr), kvol, level_out.cap, _lib.ptr(level_out.n_dev), level_in.cap, rcap, _lib.ptr(book))
+                        self.ops.append(("tilebook", lambda st, a=ab: _lib.check(L.pvx_tilebook_build(*a, st), "pvx_tilebook_build")))
             args = (_lib.ptr(feat_in), level_in.cap, cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr), kvol, level_out.cap,
                     _lib.ptr(level_out.n_dev), cout, self.code, _lib.ptr(scale), _lib.ptr(shift),
                     _lib.ptr(residual_buf) if residual_buf is not None else None, 1 if spec.relu else 0, _lib.ptr(out),

@@ -167,3 +167,46 @@ def test_rolling_form_small_counts_and_long_lines(cuda_device):
             want, _ = run_conv(dev, feat, w, nbr_t, n_live, 32, 32, 2, residual=rr)
             got, _ = run_conv(dev, feat, w, nbr_t, n_live, 32, 32, 2, book=book, rcap=rcap, residual=rr)
             assert torch.equal(got, want), (live, rr is None)
+
+
+@pytest.mark.parametrize("sort", [True, False])
+def test_fused_subm_rulebook_and_book(cuda_device, sort):
+    """pvx_subm_rulebook_tb = pvx_subm_rulebook + pvx_tilebook_build in one launch: same rulebook, same book bytes (live count
+    below the capacity, rows in key order and shuffled, two window sizes)"""
+    L = _lib.lib()
+    dev = cuda_device
+    shape, batch = [10, 50, 300], 2
+    coords = sites(13, batch, shape, 40000, sort)
+    n = len(coords)
+    cap = n + 777
+    c4 = np.zeros((cap, 4), np.int32)
+    c4[:n] = coords
+    coords_t = torch.from_numpy(c4).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    s3 = _lib.int3(shape)
+    idx = torch.empty(L.pvx_site_index_bytes(batch, s3), dtype=torch.uint8, device=dev)
+    ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, s3), dev)
+    perm = torch.empty(cap, dtype=torch.int32, device=dev)
+    nu = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(L.pvx_site_index_build(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), _lib.ptr(nu),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "index")
+    k3, d3 = _lib.int3([3, 3, 3]), _lib.int3([1, 1, 1])
+    nbr_a = torch.full((27, cap), -7, dtype=torch.int32, device=dev)
+    nbr_b = torch.full((27, cap), -7, dtype=torch.int32, device=dev)
+    _lib.check(L.pvx_subm_rulebook(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), k3, d3,
+                                   _lib.ptr(nbr_a), _lib.stream()), "rulebook")
+    assert np.array_equal(nbr_a[:, :n].cpu().numpy(), loader.subm_rulebook(coords, shape, (3, 3, 3)))
+    for rcap in (440, 896):
+        book_a = torch.zeros(L.pvx_tilebook_bytes(cap), dtype=torch.uint8, device=dev)
+        book_b = torch.zeros(L.pvx_tilebook_bytes(cap), dtype=torch.uint8, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_a), 27, cap, _lib.ptr(n_dev), cap, rcap, _lib.ptr(book_a), _lib.stream()), "build")
+        nbr_b.fill_(-7)
+        _lib.check(L.pvx_subm_rulebook_tb(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), d3,
+                                          _lib.ptr(nbr_b), rcap, _lib.ptr(book_b), _lib.stream()), "fused")
+        assert torch.equal(nbr_a, nbr_b)                      # rows past the live count untouched by both
+        tiles = (n + 255) // 256
+        a = book_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+        b = book_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+        assert np.array_equal(a[:, :7], b[:, :7]) and np.array_equal(a[:, 8:], b[:, 8:])
+    assert L.pvx_subm_rulebook_tb(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), d3,
+                                  _lib.ptr(nbr_b), 0, _lib.ptr(book_b), None) == -1
