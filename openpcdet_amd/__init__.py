@@ -9,11 +9,13 @@ import sys
 __version__ = "0.1.0"
 
 
-def install_as_spconv(also_torch_scatter=True):
+def install_as_spconv(also_torch_scatter=True, v1_voxel_generators=False):
     """Register this package's stand-ins under the module names pcdet imports: `spconv`, `spconv.pytorch`,
     `spconv.utils`, `spconv.constants`, `cumm.tensorview` (pcdet/utils/spconv_utils.py:3-10,
     pcdet/datasets/processor/data_processor.py:9-13,19-27) and, unless also_torch_scatter is False, `torch_scatter`
-    (scatter_mean / scatter_max, pcdet/models/backbones_3d/vfe/dynamic_*_vfe.py:5-9).  Call before importing pcdet."""
+    (scatter_mean / scatter_max, pcdet/models/backbones_3d/vfe/dynamic_*_vfe.py:5-9).  v1_voxel_generators=True also exports
+    spconv 1.x's `VoxelGenerator` / `VoxelGeneratorV2` from `spconv.utils`, which sends the reference's wrapper down its v1
+    branch (data_processor.py:18-35,46-52) instead of the 2.x one.  Call before importing pcdet."""
     import types
 
     from . import spconv as sp
@@ -33,6 +35,11 @@ def install_as_spconv(also_torch_scatter=True):
     sys.modules["spconv.pytorch.utils"] = putils
     sys.modules["spconv.core"] = core
     sp.pytorch, sp.utils = pytorch, utils
+    for name in ("VoxelGenerator", "VoxelGeneratorV2"):
+        if v1_voxel_generators:
+            setattr(utils, name, getattr(voxelize, name))
+        elif hasattr(utils, name):
+            delattr(utils, name)
     cumm = types.ModuleType("cumm")
     tv = types.ModuleType("cumm.tensorview")
     tv.from_numpy = voxelize.tensorview.from_numpy

@@ -140,6 +140,42 @@ class Point2VoxelCPU3d:
         return _TvTensor(v), _TvTensor(c), _TvTensor(n)
 
 
+class VoxelGenerator:
+    """spconv 1.0's `spconv.utils.VoxelGenerator` as data_processor.py:23-35,47,52 uses it: keyword constructor without the
+    point-feature count (taken from the first cloud), `generate(points ndarray)` -> (voxels, coordinates, num_points) ndarrays.
+    Not exported from the `spconv.utils` stand-in unless `install_as_spconv(v1_voxel_generators=True)` asks for it: the
+    reference tries the v1 names first and would otherwise leave its 2.x branch."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
+        self._args = (list(voxel_size), list(point_cloud_range), int(max_num_points), int(max_voxels))
+        self._impl = None
+
+    def _run(self, points):
+        pts = torch.from_numpy(np.ascontiguousarray(points, np.float32)) if isinstance(points, np.ndarray) else points
+        if pts.dim() != 2:
+            raise ValueError("points must be [N, C]")
+        if self._impl is None or self._impl[0] != pts.shape[1]:
+            vs, rng, t, m = self._args
+            self._impl = (pts.shape[1], PointToVoxel(vs, rng, pts.shape[1], m, t))
+        v, c, n = self._impl[1](pts.cuda())
+        return v.cpu().numpy(), c.cpu().numpy(), n.cpu().numpy()
+
+    def generate(self, points, max_voxels=None):
+        if max_voxels is not None and int(max_voxels) != self._args[3]:
+            self._args = self._args[:3] + (int(max_voxels),)
+            self._impl = None
+        return self._run(points)
+
+
+class VoxelGeneratorV2(VoxelGenerator):
+    """spconv 1.2's variant: `generate` returns the dict data_processor.py:48-50 unpacks."""
+
+    def generate(self, points, max_voxels=None):
+        voxels, coordinates, num_points = super().generate(points, max_voxels)
+        return {"voxels": voxels, "coordinates": coordinates, "num_points_per_voxel": num_points,
+                "voxel_num": int(voxels.shape[0])}
+
+
 class VoxelGeneratorWrapper:
     """data_processor.py:16-61: generate(points ndarray) -> (voxels, coordinates, num_points) ndarrays."""
 

@@ -81,6 +81,17 @@ def test_determinism_and_wrappers(cuda_device):
                                        max_num_points_per_voxel=cfg["T"], max_num_voxels=cfg["max_voxels"])
     voxels, coords, num = w.generate(pts)
     assert isinstance(voxels, np.ndarray) and np.array_equal(coords, a["coords"]) and np.array_equal(num, a["num_points"])
+    # spconv 1.x generators (data_processor.py:18-35,46-52): tuple and dict returns, point-feature count taken from the cloud
+    g1 = voxelize.VoxelGenerator(voxel_size=cfg["voxel"], point_cloud_range=cfg["range"], max_num_points=cfg["T"],
+                                 max_voxels=cfg["max_voxels"])
+    v1, c1, n1 = g1.generate(pts)
+    assert np.array_equal(v1.view(np.uint32), voxels.view(np.uint32)) and np.array_equal(c1, coords) and np.array_equal(n1, num)
+    d2 = voxelize.VoxelGeneratorV2(voxel_size=cfg["voxel"], point_cloud_range=cfg["range"], max_num_points=cfg["T"],
+                                   max_voxels=cfg["max_voxels"]).generate(pts[:, :4])
+    want4 = loader.voxelize_hard(np.ascontiguousarray(pts[:, :4]), cfg["voxel"], cfg["range"], cfg["T"], cfg["max_voxels"])
+    assert isinstance(d2, dict) and d2["voxel_num"] == len(want4[1])
+    assert np.array_equal(d2["coordinates"], want4[1]) and np.array_equal(d2["num_points_per_voxel"], want4[2])
+    assert np.array_equal(d2["voxels"].view(np.uint32), want4[0].view(np.uint32))
     # stand-alone MeanVFE kernel on the padded tensor
     mv = voxelize.mean_vfe(torch.from_numpy(voxels).to(cuda_device), torch.from_numpy(num).to(cuda_device).float())
     assert np.array_equal(mv.cpu().numpy().view(np.uint32), a["mean"].view(np.uint32))

@@ -65,7 +65,13 @@ def test_install_as_spconv_registers_modules():
     assert callable(torch_scatter.scatter_mean) and callable(torch_scatter.scatter_max)
     from cumm import tensorview as tv
     assert callable(tv.from_numpy)
-    # also_torch_scatter=False leaves torch_scatter alone
+    # the 1.x generator names are opt-in: the reference tries them first (data_processor.py:18-27) and would leave its 2.x branch
+    import spconv.utils as spu
+    assert hasattr(spu, "Point2VoxelCPU3d") and not hasattr(spu, "VoxelGeneratorV2") and not hasattr(spu, "VoxelGenerator")
+    openpcdet_amd.install_as_spconv(v1_voxel_generators=True)
+    from spconv.utils import VoxelGeneratorV2, VoxelGenerator     # noqa: F401
+    openpcdet_amd.install_as_spconv()
+    assert not hasattr(spu, "VoxelGeneratorV2")
     saved = sys.modules.pop("torch_scatter")
     try:
         openpcdet_amd.install_as_spconv(also_torch_scatter=False)
