@@ -118,45 +118,65 @@ __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// exclusive scan of each frame's nb block sums in place (ONE workgroup walks the frames in order), per-frame voxel
-// count -> num_voxels[f] (clamped to max_voxels).  Batch mode (row_bases != NULL): frame f's rows start at
-// row_bases[f] = sum of the earlier frames' counts and *row_total = min(sum of all, row_capacity).
-__global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(int* __restrict__ block_sums, int nb, int frames, int max_voxels,
+// exclusive scan of each frame's nb block sums (block_sums -> block_offsets), ONE workgroup per frame; per-frame voxel count ->
+// num_voxels[f] (clamped to max_voxels).  Batch mode (row_bases != NULL): frame f's rows start at row_bases[f] = sum of the earlier
+// frames' counts, which workgroup f adds up itself from their raw block sums (one wave per earlier frame; nothing waits for
+// another workgroup, which is why the scan is not in place), and *row_total = min(sum of all, row_capacity) comes from the last one.
+__global__ __launch_bounds__(kScanBlk) void vox_scan_blocks_kernel(const int* __restrict__ block_sums, int* __restrict__ block_offsets,
+                                                                    int nb, int frames, int max_voxels,
                                                                     int* __restrict__ num_voxels, int* __restrict__ row_bases,
                                                                     int row_capacity, int* __restrict__ row_total) {
     __shared__ int buf[kScanBlk];
     __shared__ int carry_s;
+    __shared__ int totals_s[kScanBlk / 64];
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int running = 0;
-    for (int f = 0; f < frames; f++) {
-        int* sums = block_sums + (size_t)f * nb;
-        if (threadIdx.x == 0) carry_s = 0;
-        __syncthreads();
-        for (int base = 0; base < nb; base += kScanBlk) {
-            const int i = base + threadIdx.x;
-            const int v = i < nb ? sums[i] : 0;
-            buf[threadIdx.x] = v;
-            __syncthreads();
-            for (int off = 1; off < kScanBlk; off <<= 1) {   // Hillis-Steele inclusive scan in LDS
-                const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
-                __syncthreads();
-                buf[threadIdx.x] += t;
-                __syncthreads();
+    if (row_bases || row_total) {
+        for (int base = 0; base < f; base += kScanBlk / 64) {     // f is uniform over the workgroup: so are the barriers
+            const int ff = base + wave;
+            int part = 0;
+            if (ff < f) {
+                const int* src = block_sums + (size_t)ff * nb;
+                for (int i = lane; i < nb; i += 64) part += src[i];
             }
-            const int carry = carry_s;
-            if (i < nb) sums[i] = carry + buf[threadIdx.x] - v;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (lane == 0) totals_s[wave] = part < max_voxels ? part : max_voxels;
             __syncthreads();
-            if (threadIdx.x == kScanBlk - 1) carry_s = carry + buf[kScanBlk - 1];
+            for (int w = 0; w < kScanBlk / 64; w++) running += totals_s[w];
             __syncthreads();
         }
-        const int total = carry_s < max_voxels ? carry_s : max_voxels;
-        if (threadIdx.x == 0) {
-            num_voxels[f] = total;
-            if (row_bases) row_bases[f] = running;
+    }
+    const int* sums = block_sums + (size_t)f * nb;
+    int* offs = block_offsets + (size_t)f * nb;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += kScanBlk) {
+        const int i = base + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlk; off <<= 1) {   // Hillis-Steele inclusive scan in LDS
+            const int t = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
         }
-        running += total;
+        const int carry = carry_s;
+        if (i < nb) offs[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlk - 1) carry_s = carry + buf[kScanBlk - 1];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && row_total) row_total[0] = running < row_capacity ? running : row_capacity;
+    const int total = carry_s < max_voxels ? carry_s : max_voxels;
+    if (threadIdx.x == 0) {
+        num_voxels[f] = total;
+        if (row_bases) row_bases[f] = running;
+        if (row_total && f == frames - 1) {
+            const long long all = (long long)running + total;
+            row_total[0] = all < row_capacity ? (int)all : row_capacity;
+        }
+    }
 }
 
 // First points are finished here: slot 0 of their voxel's list, their point_to_voxel entry, and slot_of_point[i] = kFirstDone so
@@ -327,7 +347,7 @@ size_t table_capacity(int n) {
 }
 
 struct VoxWorkspace {
-    unsigned long long* table; int* lists; int* vid_of_slot; int* slot_of_point; int* block_sums; int* row_bases;
+    unsigned long long* table; int* lists; int* vid_of_slot; int* slot_of_point; int* block_sums; int* block_offsets; int* row_bases;
 };
 
 // the table is filled with 0xff, the lists with 0x7f: two memsets per call
@@ -339,9 +359,10 @@ void carve(C& c, int frames, int n, int max_voxels, int T, VoxWorkspace* w) {
     auto vs = c.template take<int>(F * cap);
     auto sp = c.template take<int>(F * (size_t)(n > 0 ? n : 1));
     auto bs = c.template take<int>(F * (size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
+    auto bo = c.template take<int>(F * (size_t)PVX_CDIV(n > 0 ? n : 1, kScanBlk));
     auto rb = c.template take<int>(F);
     if (w) { w->table = (unsigned long long*)k; w->lists = (int*)fl;
-             w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp; w->block_sums = (int*)bs; w->row_bases = (int*)rb; }
+             w->vid_of_slot = (int*)vs; w->slot_of_point = (int*)sp; w->block_sums = (int*)bs; w->block_offsets = (int*)bo; w->row_bases = (int*)rb; }
 }
 
 struct SizerShim {   // gives PvxSizer the pointer-returning interface carve() expects
@@ -395,11 +416,11 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
                        w.block_sums);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(1), dim3(kScanBlk), 0, st, w.block_sums, nb_scan, frames, max_voxels, o.num_voxels,
+    hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(frames), dim3(kScanBlk), 0, st, w.block_sums, w.block_offsets, nb_scan, frames, max_voxels, o.num_voxels,
                        o.batch ? w.row_bases : nullptr, o.row_capacity, o.batch ? o.row_end_dev : nullptr);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
-                       w.block_sums, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
+                       w.block_offsets, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
                        o.row_capacity, w.lists, T, o.point_to_voxel);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,

@@ -106,6 +106,21 @@ def test_rulebook_edge_cases(cuda_device):
     assert np.array_equal(d.out_indices.cpu().numpy(), oc) and np.array_equal(d.nbr.cpu().numpy(), nbr)
 
 
+def test_rulebooks_long_site_index(cuda_device):
+    """a 5-frame nuScenes-sized grid: 6.6 M index words = 6.5 k block sums, the length at which the block-sum scan keeps every
+    chunk in registers (csrc/scan_util.h) -- submanifold and strided tables bit-exact, as everywhere"""
+    rng = np.random.default_rng(11)
+    batch, shape = 5, [41, 1440, 1440]
+    coords = clustered_sites(rng, batch, shape, 60000)
+    x = make_tensor(coords, np.zeros((coords.shape[0], 4), np.float32), shape, batch, cuda_device, torch.float32)
+    sub = spconv.SubMConv3d(4, 4, 3).to(cuda_device)
+    assert np.array_equal(sub._build_subm(x).nbr.cpu().numpy(), loader.subm_rulebook(coords, shape, 3))
+    down = spconv.SparseConv3d(4, 4, 3, stride=1, padding=1).to(cuda_device)      # stride 1: the OUTPUT index is as long
+    d = down._build_strided(x)
+    oc, nbr, _ = loader.sparse_rulebook(coords, shape, 3, 1, 1)
+    assert np.array_equal(d.out_indices.cpu().numpy(), oc) and np.array_equal(d.nbr.cpu().numpy(), nbr)
+
+
 @pytest.mark.parametrize("name,seed", [("nuscenes_centerpoint", 3), ("kitti_second", 1)])
 def test_rulebooks_full_frame(name, seed, cuda_device):
     """config-scale site sets (from the oracle voxelizer on the synthetic frame): all 9 rulebooks of the
