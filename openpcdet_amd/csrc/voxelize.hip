@@ -104,7 +104,11 @@ __device__ __forceinline__ int block_rank(bool flag, int* wave_sums, int& block_
     return before + in_wave;
 }
 
-__global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __restrict__ slot_of_point,
+// first points are marked in slot_of_point (bit 30; the table has at most 2^30 slots, checked on the host), so that
+// vox_assign_kernel goes back to the table for them only -- the other two thirds of the points skip that random read
+constexpr int kFirstBit = 0x40000000;
+
+__global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(int* __restrict__ slot_of_point,
                                                                     const unsigned long long* __restrict__ table, int n,
                                                                     size_t table_slots, int* __restrict__ block_sums) {
     __shared__ int wave_sums[kScanBlk / 64];
@@ -112,7 +116,11 @@ __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(const int* __
     slot_of_point += f * (size_t)n; table += f * table_slots; block_sums += f * gridDim.x;
     const int i = blockIdx.x * kScanBlk + threadIdx.x;
     bool flag = false;
-    if (i < n) { const int s = slot_of_point[i]; flag = s >= 0 && (unsigned)table[s] == (unsigned)i; }
+    if (i < n) {
+        const int s = slot_of_point[i];
+        flag = s >= 0 && (unsigned)table[s] == (unsigned)i;
+        if (flag) slot_of_point[i] = s | kFirstBit;
+    }
     int total;
     block_rank(flag, wave_sums, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -204,7 +212,10 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(int* __restrict__ 
     bool flag = false;
     int s = -1;
     unsigned long long word = 0;
-    if (i < n) { s = slot_of_point[i]; if (s >= 0) { word = table[s]; flag = (unsigned)word == (unsigned)i; } }
+    if (i < n) {
+        s = slot_of_point[i];
+        if (s >= 0 && (s & kFirstBit)) { s &= ~kFirstBit; flag = true; word = table[s]; }
+    }
     int total;
     const int rank = block_offsets[blockIdx.x] + block_rank(flag, wave_sums, total);
     if (flag) {
@@ -320,6 +331,90 @@ __global__ __launch_bounds__(kBlk) void vox_gather_kernel(const float* __restric
     }
 }
 
+// The same gather with one thread per VOXEL (T <= 16, c <= 8): the list is read once instead of once per channel, a point's c
+// values come from one 4c-byte run, and the mean row leaves as one or two 16-byte stores when it is 16 half-precision values wide.
+// Same sums in the same order (entries past the count contribute nothing: the running sum starts at +0 and can never be -0, so
+// leaving out their "+ 0.f" changes no bit).
+constexpr int kRowsT = 16, kRowsC = 8;
+
+__global__ __launch_bounds__(kBlk) void vox_gather_rows_kernel(const float* __restrict__ pts, int n, int c, int T,
+                                                                const int* __restrict__ lists, int max_voxels,
+                                                                const int* __restrict__ num_voxels,
+                                                                float* __restrict__ voxels, int* __restrict__ num_per_voxel,
+                                                                void* __restrict__ mean, int mean_stride, int mean_dtype,
+                                                                const int* __restrict__ row_base_dev, int row_capacity,
+                                                                int vector_rows) {
+    const int v = blockIdx.x * kBlk + threadIdx.x;
+    const size_t f = blockIdx.y;
+    if (v >= num_voxels[f]) return;
+    pts += f * (size_t)n * c; lists += f * (size_t)max_voxels * T;
+    if (voxels) voxels += f * (size_t)max_voxels * T * c;
+    if (num_per_voxel) num_per_voxel += f * (size_t)max_voxels;
+    const long long row = (long long)(row_base_dev ? row_base_dev[f] : 0) + v;
+    const int* L = lists + (size_t)v * T;
+    int li[kRowsT];
+#pragma unroll
+    for (int t = 0; t < kRowsT; t++) li[t] = t < T ? L[t] : kSentinel;
+    int cnt = 0;
+    float sum[kRowsC];
+#pragma unroll
+    for (int k = 0; k < kRowsC; k++) sum[k] = 0.f;
+#pragma unroll
+    for (int t0 = 0; t0 < kRowsT; t0 += 4) {
+        if (t0 >= T) break;
+        float val[4][kRowsC];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool ok = li[t0 + j] < n;            // slots past T hold the sentinel
+            const float* src = pts + (size_t)(ok ? li[t0 + j] : 0) * c;
+#pragma unroll
+            for (int k = 0; k < kRowsC; k++) val[j][k] = (ok && k < c) ? src[k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (t0 + j < T) {
+                if (li[t0 + j] < n) {
+                    cnt++;
+#pragma unroll
+                    for (int k = 0; k < kRowsC; k++) sum[k] += val[j][k];
+                }
+                if (voxels) {
+                    float* dst = voxels + ((size_t)v * T + t0 + j) * c;
+#pragma unroll
+                    for (int k = 0; k < kRowsC; k++) if (k < c) dst[k] = val[j][k];
+                }
+            }
+        }
+    }
+    if (num_per_voxel) num_per_voxel[v] = cnt;
+    if (!mean || row >= row_capacity) return;
+    const float div = (float)(cnt < 1 ? 1 : cnt);
+    float m[kRowsC];
+#pragma unroll
+    for (int k = 0; k < kRowsC; k++) m[k] = k < c ? sum[k] / div : 0.f;
+    if (vector_rows) {                                  // 16 half-precision values per row, 16-byte aligned base (host-checked)
+        unsigned short h[kRowsC];
+#pragma unroll
+        for (int k = 0; k < kRowsC; k++) {
+            if (mean_dtype == PVX_F16) { const _Float16 x = (_Float16)m[k]; h[k] = __builtin_bit_cast(unsigned short, x); }
+            else { const __bf16 x = (__bf16)m[k]; h[k] = __builtin_bit_cast(unsigned short, x); }
+        }
+        uint4* dst = reinterpret_cast<uint4*>((unsigned short*)mean + row * 16);
+        dst[0] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16),
+                            h[6] | ((unsigned)h[7] << 16));
+        dst[1] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    for (int ch = 0; ch < mean_stride; ch++) {
+        float x = 0.f;
+#pragma unroll
+        for (int k = 0; k < kRowsC; k++) if (k == ch) x = m[k];
+        if (mean_dtype == PVX_F32) ((float*)mean)[row * mean_stride + ch] = x;
+        else if (mean_dtype == PVX_F16) ((_Float16*)mean)[row * mean_stride + ch] = (_Float16)x;
+        else ((__bf16*)mean)[row * mean_stride + ch] = (__bf16)x;
+    }
+}
+
 __global__ void vox_row_end_kernel(const int* __restrict__ num_voxels, const int* __restrict__ row_base_dev, int row_capacity,
                                    int* __restrict__ row_end_dev) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -406,6 +501,7 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     carve(cv, frames, n, max_voxels, T, &w);
     if (!cv.ok()) return PVX_ERR_WORKSPACE;
     const size_t cap = table_capacity(n), F = (size_t)frames;
+    if (cap > ((size_t)1 << 30)) return PVX_ERR_RANGE;   // slot numbers share an int with kFirstBit (~700 M points per frame)
     PVX_CHECK_HIP(hipMemsetAsync(w.table, 0xff, F * cap * sizeof(unsigned long long), st));
     PVX_CHECK_HIP(hipMemsetAsync(w.lists, 0x7f, F * (size_t)max_voxels * T * sizeof(int), st));
     const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
@@ -426,10 +522,18 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,
                        max_voxels, w.lists, o.point_to_voxel);
     PVX_CHECK_LAUNCH();
-    const long long work = (long long)max_voxels * o.mean_stride;
-    hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk), frames), dim3(kBlk), 0, st, points, n, c, T,
-                       w.lists, max_voxels, o.num_voxels, o.voxels, o.num_points_per_voxel, o.mean, o.mean_stride, o.mean_dtype,
-                       row_bases, o.row_capacity);
+    static const bool rows_form = [] { const char* e = getenv("PVX_VOX_GATHER_ROWS"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (rows_form && T <= kRowsT && c <= kRowsC) {
+        const int vector_rows = o.mean && o.mean_dtype != PVX_F32 && o.mean_stride == 16 && ((uintptr_t)o.mean & 15) == 0;
+        hipLaunchKernelGGL(vox_gather_rows_kernel, dim3((unsigned)PVX_CDIV(max_voxels, kBlk), frames), dim3(kBlk), 0, st, points, n, c,
+                           T, w.lists, max_voxels, o.num_voxels, o.voxels, o.num_points_per_voxel, o.mean, o.mean_stride,
+                           o.mean_dtype, row_bases, o.row_capacity, vector_rows);
+    } else {
+        const long long work = (long long)max_voxels * o.mean_stride;
+        hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk), frames), dim3(kBlk), 0, st, points, n, c,
+                           T, w.lists, max_voxels, o.num_voxels, o.voxels, o.num_points_per_voxel, o.mean, o.mean_stride,
+                           o.mean_dtype, row_bases, o.row_capacity);
+    }
     PVX_CHECK_LAUNCH();
     if (o.row_end_dev && !o.batch) {
         hipLaunchKernelGGL(vox_row_end_kernel, dim3(1), dim3(64), 0, st, o.num_voxels, o.row_base_dev, o.row_capacity, o.row_end_dev);
