@@ -257,9 +257,20 @@ __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict_
     // arrive in index order, so a voxel's m-th point would otherwise walk m occupied slots).
     // Slot 0 was written by vox_assign (the cell's first point, which never gets here), so everybody starts at slot 1:
     // single-point voxels cost no atomic at all.
+    // The first kAhead of those reads go out together: one round trip decides instead of one per occupied slot.
+    constexpr int kAhead = 9;
     int t0 = 1;
-    for (int t = 1; t < T; t++) {
-        if (L[t] < i) t0 = t + 1; else break;
+    {
+        int a[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) a[j] = 1 + j < T ? L[1 + j] : kSentinel;
+#pragma unroll
+        for (int j = 0; j < kAhead; j++) if (t0 == 1 + j && a[j] < i) t0 = 2 + j;
+    }
+    if (t0 == 1 + kAhead) {
+        for (int t = 1 + kAhead; t < T; t++) {
+            if (L[t] < i) t0 = t + 1; else break;
+        }
     }
     int v = i;
     for (int t = t0; t < T; t++) {
