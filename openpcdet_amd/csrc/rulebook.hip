@@ -58,6 +58,47 @@ __device__ __forceinline__ int rank_of_cached(const IndexEntry* __restrict__ idx
     return (int)craw.z + __popcll(bits & ((1ull << bit) - 1ull));
 }
 
+// All 27 lookups of a 3 x 3 x 3 neighbourhood whose x step is 1, in three dependent round trips instead of up to 27: the three
+// x-neighbours of a (dz, dy) line lie in at most two adjacent index words, so the 18 entry loads (clamped to cells of the line:
+// always readable) go out together, then the 27 optional perm loads, then the caller's stores.  (zc, yc, xc) is the centre in the
+// indexed grid (xc may lie one cell outside it: a padded strided conv), sz / sy the z / y steps.  Same values as rank_of().
+__device__ __forceinline__ void probe_3x3x3(const IndexEntry* __restrict__ idx, const int* __restrict__ perm, int b, int zc,
+                                             int yc, int xc, int sz, int sy, const Dims& s, int (&v)[27]) {
+    const bool bok = b >= 0 && b < s.b;
+    const int xa = xc - 1 < 0 ? 0 : (xc - 1 >= s.w ? s.w - 1 : xc - 1), xb = xc + 1 < 0 ? 0 : (xc + 1 >= s.w ? s.w - 1 : xc + 1);
+    long long base[9];
+    uint4 lo[9], hi[9];
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        const int z = zc + (l / 3 - 1) * sz, y = yc + (l % 3 - 1) * sy;
+        const bool lok = bok && z >= 0 && z < s.d && y >= 0 && y < s.h;
+        base[l] = lok ? lin_key(b, z, y, 0, s) : -1;
+        const long long kb = lok ? base[l] : 0;
+        lo[l] = *reinterpret_cast<const uint4*>(idx + ((kb + xa) >> 6));
+        hi[l] = *reinterpret_cast<const uint4*>(idx + ((kb + xb) >> 6));
+    }
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int x = xc - 1 + dx;
+            int r = -1;
+            if (base[l] >= 0 && x >= 0 && x < s.w) {
+                const long long key = base[l] + x;
+                const uint4 raw = (key >> 6) == ((base[l] + xa) >> 6) ? lo[l] : hi[l];
+                const unsigned long long bits = ((unsigned long long)raw.y << 32) | raw.x;
+                const int bit = (int)(key & 63);
+                if ((bits >> bit) & 1ull) r = (int)raw.z + __popcll(bits & ((1ull << bit) - 1ull));
+            }
+            v[l * 3 + dx] = r;
+        }
+    }
+    if (perm) {
+#pragma unroll
+        for (int k = 0; k < 27; k++) v[k] = v[k] >= 0 ? perm[v[k]] : -1;
+    }
+}
+
 // every kernel takes (n, n_dev): n is the row capacity the grid is sized for, *n_dev (when given) the live row
 // count produced by an earlier kernel on the same stream -- no host round trip for data-dependent sizes
 __device__ __forceinline__ int live_rows(int n, const int* __restrict__ n_dev) {
@@ -128,6 +169,13 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_kernel(const int* __restri
     const int o = blockIdx.x * kBlk + threadIdx.x;
     if (o >= live_rows(n, n_dev)) return;   // nbr keeps the CAPACITY n as its row stride
     const int4 c = reinterpret_cast<const int4*>(coords)[o];
+    if (kd == 3 && kh == 3 && kw == 3 && dw == 1) {            // uniform over the launch
+        int v[27];
+        probe_3x3x3(idx, perm, c.x, c.y, c.z, c.w, dd, dh, s, v);
+#pragma unroll
+        for (int k = 0; k < 27; k++) nbr[(size_t)k * n + o] = v[k];
+        return;
+    }
     int k = 0;
     long long cword = -1;
     uint4 craw = make_uint4(0u, 0u, 0u, 0u);
@@ -168,6 +216,11 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
         const int4 c = reinterpret_cast<const int4*>(coords)[o];
         long long cword = -1;
         uint4 craw = make_uint4(0u, 0u, 0u, 0u);
+        if (dw == 1) {                                          // uniform over the launch
+            probe_3x3x3(idx, perm, c.x, c.y, c.z, c.w, dd, dh, s, v);
+#pragma unroll
+            for (int k = 0; k < kTbK; k++) nbr[(size_t)k * n + o] = v[k];
+        } else
 #pragma unroll
         for (int k = 0; k < kTbK; k++) {
             const int z = c.y + (k / 9 - 1) * dd, y = c.z + ((k / 3) % 3 - 1) * dh, x = c.w + (k % 3 - 1) * dw;
@@ -279,6 +332,14 @@ __global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __re
     const int o = blockIdx.x * kBlk + threadIdx.x;
     if (o >= live_rows(n_out, n_out_dev)) return;
     const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
+    if (g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 && g.dil[2] == 1) {      // uniform over the launch
+        int v[27];
+        probe_3x3x3(in_idx, in_perm, c.x, c.y * g.s[0] - g.p[0] + g.dil[0], c.z * g.s[1] - g.p[1] + g.dil[1],
+                    c.w * g.s[2] - g.p[2] + 1, g.dil[0], g.dil[1], g.in, v);
+#pragma unroll
+        for (int k = 0; k < 27; k++) nbr[(size_t)k * n_out + o] = v[k];
+        return;
+    }
     int k = 0;
     long long cword = -1;
     uint4 craw = make_uint4(0u, 0u, 0u, 0u);
