@@ -241,6 +241,14 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
 // Scattered global atomics run at a few tens of G/s on this chip and serialise when many lanes hit one word, which is
 // exactly what sorted inputs do (x-neighbours share an output word).  So the bits of a workgroup are first merged in a
 // small LDS hash (word -> 64-bit mask, LDS atomics), and each distinct word costs ONE global atomicOr.
+// t / s when s divides t (t >= 0); strides 1 and 2 -- all this backbone family uses -- without the integer division sequence
+__device__ __forceinline__ bool div_exact(int t, int s, int& q) {
+    if (s == 1) { q = t; return true; }
+    if (s == 2) { q = t >> 1; return !(t & 1); }
+    q = t / s;
+    return q * s == t;
+}
+
 constexpr int kMergeSlots = 1024;
 constexpr unsigned long long kNoWord = ~0ull;
 
@@ -258,19 +266,16 @@ __global__ __launch_bounds__(kBlk) void conv_out_setbits_kernel(const int* __res
         if (c.x >= 0 && c.x < g.in.b) {
             for (int a = 0; a < g.k[0]; a++) {
                 const int tz = c.y + g.p[0] - a * g.dil[0];
-                if (tz < 0 || tz % g.s[0] != 0) continue;
-                const int oz = tz / g.s[0];
-                if (oz >= g.out.d) continue;
+                int oz;
+                if (tz < 0 || !div_exact(tz, g.s[0], oz) || oz >= g.out.d) continue;
                 for (int bq = 0; bq < g.k[1]; bq++) {
                     const int ty = c.z + g.p[1] - bq * g.dil[1];
-                    if (ty < 0 || ty % g.s[1] != 0) continue;
-                    const int oy = ty / g.s[1];
-                    if (oy >= g.out.h) continue;
+                    int oy;
+                    if (ty < 0 || !div_exact(ty, g.s[1], oy) || oy >= g.out.h) continue;
                     for (int cq = 0; cq < g.k[2]; cq++) {
                         const int tx = c.w + g.p[2] - cq * g.dil[2];
-                        if (tx < 0 || tx % g.s[2] != 0) continue;
-                        const int ox = tx / g.s[2];
-                        if (ox >= g.out.w) continue;
+                        int ox;
+                        if (tx < 0 || !div_exact(tx, g.s[2], ox) || ox >= g.out.w) continue;
                         const long long key = lin_key(c.x, oz, oy, ox, g.out);
                         const unsigned long long word = (unsigned long long)(key >> 6), bit = 1ull << (key & 63);
                         unsigned h = (unsigned)((word * 0x9E3779B97F4A7C15ull) >> 54) & (kMergeSlots - 1);
@@ -623,12 +628,25 @@ __global__ __launch_bounds__(kBlk) void sort_sites_kernel(const int* __restrict_
     const int i = blockIdx.x * kBlk + threadIdx.x;
     if (i >= live_rows(n_cap, n_dev)) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    // rows of up to 32 bytes (the voxel features of a 16-channel half-precision level 0) are requested before the rank lookup
+    // instead of behind it: one round trip less on every lane
+    uint4 head[2];
+    const bool small = row_u4 <= 2;
+    if (small) {
+        head[0] = rows[(size_t)i * row_u4];
+        head[1] = row_u4 == 2 ? rows[(size_t)i * row_u4 + 1] : make_uint4(0u, 0u, 0u, 0u);
+    }
     int r = -1;
     if (c.x >= 0 && c.x < s.b && c.y >= 0 && c.y < s.d && c.z >= 0 && c.z < s.h && c.w >= 0 && c.w < s.w)
         r = rank_of(idx, lin_key(c.x, c.y, c.z, c.w, s));
     if (rank_out) rank_out[i] = r;
     if (r < 0 || r >= n_cap) return;
     reinterpret_cast<int4*>(coords_out)[r] = c;
+    if (small) {
+        rows_out[(size_t)r * row_u4] = head[0];
+        if (row_u4 == 2) rows_out[(size_t)r * row_u4 + 1] = head[1];
+        return;
+    }
     for (int q = 0; q < row_u4; q++) rows_out[(size_t)r * row_u4 + q] = rows[(size_t)i * row_u4 + q];
 }
 
