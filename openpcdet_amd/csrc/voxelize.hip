@@ -13,14 +13,14 @@
 //               with atomicMin only if it carries a smaller index, so every occupied slot ends up knowing the FIRST
 //               point of its cell at ~1.1 atomics per point;
 //   2. rank     point i is a "first point" iff first[slot(i)] == i.  A wavefront ballot + popcount prefix
-//               (block sums scanned by one workgroup) ranks the first points in input order: that rank IS
+//               (block sums scanned by one workgroup per frame) ranks the first points in input order: that rank IS
 //               the sequential voxel id.  Cells with rank >= max_voxels are exactly the ones the sequential
 //               algorithm refuses;
 //   3. bucket   (slot 0 of a cell's list is its first point, stored by the rank kernel) every other point of a kept cell
 //               pushes its index through an atomicMin cascade over the cell's remaining T - 1
 //               slots; whatever the arrival order, slot t ends up holding the (t+1)-th smallest point index;
-//   4. gather   one thread per (voxel, channel) copies the <= T points in order, zero-fills the rest,
-//               counts them and (fused MeanVFE) divides the running sum by max(count, 1).
+//   4. gather   one thread per voxel (per (voxel, channel) when T > 16 or c > 8) copies the <= T points in order, zero-fills
+//               the rest, counts them and (fused MeanVFE) divides the running sum by max(count, 1).
 // All table traffic inside a launch is atomic (no plain re-read of a word another CU's atomic wrote);
 // kernels hand data to each other only across launch boundaries.
 #include "pvx_common.h"
