@@ -367,6 +367,15 @@ int pvx_sparse_conv_wgrad(const void* feat_in, int n_in, int cin, const void* gr
 int pvx_sparse_to_dense(const void* feat, const int* coords, int n, const int* n_dev, int c, int dtype, int batch,
                         const int* shape_dhw, void* out, void* stream);
 
+/* The same tensor for rows that are in ascending (b, z, y, x) order -- row i is the site of rank i in `index`
+ * (pvx_site_index_build of sorted rows, or the output index of pvx_conv_out_index: every level of spconv_backbone.py's
+ * strided chain, so also the tensor height_compression.py:22 densifies).  One workgroup per group of y lines writes its run
+ * of every channel plane in 8-byte stores, zeros included: no separate zero-fill, no scattered 2-byte stores.  16-bit dtypes,
+ * even c, W % 4 == 0 and a line's share of the rows within 64 KiB of LDS, else PVX_ERR_RANGE (use pvx_sparse_to_dense).  When n
+ * is 0 (with n_dev NULL) the index must still be a built (empty) one. */
+int pvx_sparse_to_dense_sorted(const void* feat, const void* index, int n, const int* n_dev, int c, int dtype, int batch,
+                               const int* shape_dhw, void* out, void* stream);
+
 /* ---- CenterPoint head decode ------------------------------------------------------------
  * Per frame: the K largest values of heatmap[b] ([C, H, W], already sigmoid-ed) in descending order (equal values: lower
  * flat index c*H*W + y*W + x first), each decoded to x, y, z, dx, dy, dz, heading[, vx, vy] with the reference's float32

@@ -121,6 +121,8 @@ SIGNATURES = {
                                       c_void_p, c_size_t, c_void_p]),
     "pvx_sparse_to_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p]),
+    "pvx_sparse_to_dense_sorted": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                           c_void_p]),
 }
 
 

@@ -318,7 +318,19 @@ class HotPathEngine:
             self.dense = torch.empty((B, self.out_channels, *cur.shape3), dtype=self.dtype, device=dev)
             ad = (_lib.ptr(cur_feat), _lib.ptr(cur.coords), cur.cap, _lib.ptr(cur.n_dev), self.out_channels, self.code, B,
                   cur.c_shape, _lib.ptr(self.dense))
-            self.ops.append(("dense", lambda st, a=ad: _lib.check(L.pvx_sparse_to_dense(*a, st), "pvx_sparse_to_dense")))
+            # the strided chain leaves its rows in key order: the line form writes the tensor once, zeros included (PVX_ENGINE_DENSE_LINES=0:
+            # zero-fill + scatter, the A/B switch and the fall-back for shapes the line form does not take)
+            w, words = cur.shape3[2], self.out_channels // 2
+            lines_ok = (os.environ.get("PVX_ENGINE_DENSE_LINES", "1") != "0" and self.dtype in (torch.bfloat16, torch.float16)
+                        and self.out_channels % 2 == 0 and w % 4 == 0 and (w + w * ((words // (4 if words % 4 == 0 else 1)) | 1)) * 4 <= 64 * 1024
+                        and len(self.levels) > 1)
+            if lines_ok:
+                al = (_lib.ptr(cur_feat), _lib.ptr(cur.index), cur.cap, _lib.ptr(cur.n_dev), self.out_channels, self.code, B,
+                      cur.c_shape, _lib.ptr(self.dense))
+                self.ops.append(("dense", lambda st, a=al: _lib.check(L.pvx_sparse_to_dense_sorted(*a, st),
+                                                                      "pvx_sparse_to_dense_sorted")))
+            else:
+                self.ops.append(("dense", lambda st, a=ad: _lib.check(L.pvx_sparse_to_dense(*a, st), "pvx_sparse_to_dense")))
         torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------------------------------------------------

@@ -238,6 +238,53 @@ def test_dense_exact(dtype, cuda_device):
     assert d.view(batch, 128 * 2, 45, 41).shape == (batch, 256, 45, 41)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_sorted_rows_exact(dtype, cuda_device):
+    """pvx_sparse_to_dense_sorted (rows in key order, found through the site index): the oracle's tensor bit for bit, every cell
+    written (the output starts as garbage), live count below the capacity, an empty frame, a full line; shapes it does not take
+    are refused"""
+    from openpcdet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    batch, shape, c = 4, [2, 37, 180], 128
+    coords = random_sites(rng, batch, shape, 9000)
+    coords = coords[coords[:, 0] != 2]                                            # frame 2 stays empty
+    full = np.array([[1, 1, 5, x] for x in range(shape[2])], np.int32)            # one full line
+    coords = np.unique(np.concatenate([coords, full], 0), axis=0)                 # np.unique sorts rows = ascending key order
+    n = len(coords)
+    cap = n + 300
+    feat = rounded(rng.normal(size=(n, c)).astype(np.float32), dtype)
+    c4 = np.zeros((cap, 4), np.int32); c4[:n] = coords
+    f_t = torch.full((cap, c), 7.0, dtype=dtype, device=cuda_device)
+    f_t[:n] = torch.from_numpy(feat).to(cuda_device).to(dtype)
+    coords_t = torch.from_numpy(c4).to(cuda_device)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=cuda_device)
+    s3 = _lib.int3(shape)
+    idx = torch.empty(L.pvx_site_index_bytes(batch, s3), dtype=torch.uint8, device=cuda_device)
+    ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, s3), cuda_device)
+    nu = torch.zeros(1, dtype=torch.int32, device=cuda_device)
+    _lib.check(L.pvx_site_index_build(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), None, _lib.ptr(nu),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "index")
+    out = torch.full((batch, c, *shape), 3.0, dtype=dtype, device=cuda_device)
+    code = _lib.DTYPE_CODE[dtype]
+    _lib.check(L.pvx_sparse_to_dense_sorted(_lib.ptr(f_t), _lib.ptr(idx), cap, _lib.ptr(n_dev), c, code, batch, s3, _lib.ptr(out),
+                                            _lib.stream()), "dense_sorted")
+    want = loader.dense(feat, coords, batch, shape)
+    assert np.array_equal(out.float().cpu().numpy(), want)
+    ref = torch.empty_like(out)
+    _lib.check(L.pvx_sparse_to_dense(_lib.ptr(f_t), _lib.ptr(coords_t), cap, _lib.ptr(n_dev), c, code, batch, s3, _lib.ptr(ref),
+                                     _lib.stream()), "dense")
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # W not a multiple of 4, odd channel count, fp32: refused, nothing launched
+    bad = _lib.int3([2, 37, 182])
+    assert L.pvx_sparse_to_dense_sorted(_lib.ptr(f_t), _lib.ptr(idx), cap, _lib.ptr(n_dev), c, code, batch, bad, _lib.ptr(out),
+                                        _lib.stream()) == -4
+    assert L.pvx_sparse_to_dense_sorted(_lib.ptr(f_t), _lib.ptr(idx), cap, _lib.ptr(n_dev), 127, code, batch, s3, _lib.ptr(out),
+                                        _lib.stream()) == -4
+    assert L.pvx_sparse_to_dense_sorted(_lib.ptr(f_t), _lib.ptr(idx), cap, _lib.ptr(n_dev), c, 0, batch, s3, _lib.ptr(out),
+                                        _lib.stream()) == -4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_epilogue_and_device_counts(dtype, cuda_device):
     """pvx_sparse_conv_fwd with folded BN (scale, shift), residual and ReLU, driven by a DEVICE row count smaller
