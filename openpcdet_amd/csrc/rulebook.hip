@@ -122,30 +122,66 @@ __global__ __launch_bounds__(kBlk) void idx_setbits_kernel(const int* __restrict
     if (flags) flags[(key >> 6) / pvx::kScanBlock] = 1;      // every writer stores the same value
 }
 
-__global__ __launch_bounds__(pvx::kScanBlock) void idx_count_kernel(const IndexEntry* __restrict__ idx, long long words,
-                                                                     int* __restrict__ block_sums, const int* __restrict__ flags) {
-    __shared__ int wave_sums[pvx::kScanBlock / 64];
+// Both passes keep the block of kScanBlock (1024) words per block sum but run it on kIdxThreads (256) threads, four consecutive
+// words each: a 1024-thread workgroup has to wait for a CU with 16 free wave slots, which the persistent conv workgroups of the
+// overlapped schedule rarely leave (idx_count ran 15x longer beside them than alone, profiles/r02_kernel_stats_overlapped_b16.csv).
+constexpr int kIdxThreads = 256, kIdxPer = pvx::kScanBlock / kIdxThreads;
+
+// exclusive prefix of v over a kIdxThreads workgroup; total -> block_total.  Two barriers.
+__device__ __forceinline__ int idx_block_scan(int v, int* wave_sums, int& block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kIdxThreads / 64; w++) {
+        const int q = wave_sums[w];
+        if (w < wave) before += q;
+        total += q;
+    }
+    __syncthreads();
+    block_total = total;
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(kIdxThreads) void idx_count_kernel(const IndexEntry* __restrict__ idx, long long words,
+                                                                 int* __restrict__ block_sums, const int* __restrict__ flags) {
+    __shared__ int wave_sums[kIdxThreads / 64];
     if (flags && flags[blockIdx.x] == 0) {                   // whole workgroup: no barrier is skipped by part of it
         if (threadIdx.x == 0) block_sums[blockIdx.x] = 0;
         return;
     }
-    const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
-    const int v = w < words ? __popcll(idx[w].bits) : 0;
+    const long long w0 = (long long)blockIdx.x * pvx::kScanBlock + (long long)threadIdx.x * kIdxPer;
+    int v = 0;
+#pragma unroll
+    for (int j = 0; j < kIdxPer; j++) v += w0 + j < words ? __popcll(idx[w0 + j].bits) : 0;
     int total;
-    pvx::block_exclusive_scan(v, wave_sums, total);
+    idx_block_scan(v, wave_sums, total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(pvx::kScanBlock) void idx_prefix_kernel(IndexEntry* __restrict__ idx, long long words,
-                                                                      const int* __restrict__ block_offsets,
-                                                                      const int* __restrict__ flags) {
-    __shared__ int wave_sums[pvx::kScanBlock / 64];
+__global__ __launch_bounds__(kIdxThreads) void idx_prefix_kernel(IndexEntry* __restrict__ idx, long long words,
+                                                                  const int* __restrict__ block_offsets,
+                                                                  const int* __restrict__ flags) {
+    __shared__ int wave_sums[kIdxThreads / 64];
     if (flags && flags[blockIdx.x] == 0) return;             // no bit in this block: its prefixes are never read
-    const long long w = (long long)blockIdx.x * pvx::kScanBlock + threadIdx.x;
-    const int v = w < words ? __popcll(idx[w].bits) : 0;
+    const long long w0 = (long long)blockIdx.x * pvx::kScanBlock + (long long)threadIdx.x * kIdxPer;
+    int p[kIdxPer], v = 0;
+#pragma unroll
+    for (int j = 0; j < kIdxPer; j++) { p[j] = w0 + j < words ? __popcll(idx[w0 + j].bits) : 0; v += p[j]; }
     int total;
-    const int ex = pvx::block_exclusive_scan(v, wave_sums, total);
-    if (w < words) idx[w].prefix = (unsigned)(block_offsets[blockIdx.x] + ex);
+    int ex = block_offsets[blockIdx.x] + idx_block_scan(v, wave_sums, total);
+#pragma unroll
+    for (int j = 0; j < kIdxPer; j++) {
+        if (w0 + j < words) idx[w0 + j].prefix = (unsigned)ex;
+        ex += p[j];
+    }
 }
 
 __global__ __launch_bounds__(kBlk) void idx_perm_kernel(const int* __restrict__ coords, int n_cap,
@@ -388,11 +424,11 @@ constexpr long long kMaxWords = 1ll << 28;   // 16 Gi cells, 4 GiB of index: bey
 
 int scan_index(IndexEntry* idx, long long words, int* block_sums, const int* flags, int* total_dev, hipStream_t st) {
     const int nb = (int)PVX_CDIV(words, (long long)pvx::kScanBlock);
-    hipLaunchKernelGGL(idx_count_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums, flags);
+    hipLaunchKernelGGL(idx_count_kernel, dim3(nb), dim3(kIdxThreads), 0, st, idx, words, block_sums, flags);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(pvx::scan_block_sums_kernel, dim3(1), dim3(pvx::kScanBlock), 0, st, block_sums, nb, -1, total_dev);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(idx_prefix_kernel, dim3(nb), dim3(pvx::kScanBlock), 0, st, idx, words, block_sums, flags);
+    hipLaunchKernelGGL(idx_prefix_kernel, dim3(nb), dim3(kIdxThreads), 0, st, idx, words, block_sums, flags);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
 }

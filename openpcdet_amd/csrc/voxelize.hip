@@ -28,7 +28,8 @@
 namespace {
 
 constexpr int kBlk = 256;
-constexpr int kScanBlk = 1024;
+constexpr int kScanBlk = 256;    // rank kernels: small workgroups find a CU beside the persistent conv workgroups (1024-thread ones waited:
+                                  // the count / scan kernels ran 15-40x longer under overlap than alone, profiles/r02_kernel_stats_overlapped_b16.csv)
 constexpr unsigned long long kEmptyKey = ~0ull;
 constexpr int kSentinel = 0x7f7f7f7f;   // what hipMemsetAsync(0x7f) leaves; larger than any point index
 
