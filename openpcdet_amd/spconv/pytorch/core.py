@@ -70,16 +70,25 @@ class _DenseFunction(torch.autograd.Function):
     of the dense gradient at the same cells (what autograd derives for the reference's indexed assignment)."""
 
     @staticmethod
-    def forward(ctx, feats, coords, batch_size, shape3):
+    def forward(ctx, feats, coords, batch_size, shape3, sorted_index=None):
         f = feats.contiguous()
         L = _lib.lib()
         dev = f.device
         c = f.shape[1]
         out = torch.empty((batch_size, c, *shape3), dtype=f.dtype, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(L.pvx_sparse_to_dense(_lib.ptr(f), _lib.ptr(coords), f.shape[0], None, c, _lib.DTYPE_CODE[f.dtype],
-                                             batch_size, _lib.int3(list(shape3)), _lib.ptr(out), _lib.stream()),
-                       "pvx_sparse_to_dense")
+            rc = -4
+            if sorted_index is not None and f.dtype in (torch.bfloat16, torch.float16) and f.shape[0] > 0:
+                # rows in key order with their site index at hand (the output of a strided conv): one pass, no zero-fill;
+                # PVX_ERR_RANGE (-4) = a shape the line form does not take
+                rc = L.pvx_sparse_to_dense_sorted(_lib.ptr(f), _lib.ptr(sorted_index), f.shape[0], None, c, _lib.DTYPE_CODE[f.dtype],
+                                                  batch_size, _lib.int3(list(shape3)), _lib.ptr(out), _lib.stream())
+                if rc != -4:
+                    _lib.check(rc, "pvx_sparse_to_dense_sorted")
+            if rc == -4:
+                _lib.check(L.pvx_sparse_to_dense(_lib.ptr(f), _lib.ptr(coords), f.shape[0], None, c, _lib.DTYPE_CODE[f.dtype],
+                                                 batch_size, _lib.int3(list(shape3)), _lib.ptr(out), _lib.stream()),
+                           "pvx_sparse_to_dense")
         ctx.save_for_backward(coords)
         return out
 
@@ -88,7 +97,7 @@ class _DenseFunction(torch.autograd.Function):
         (coords,) = ctx.saved_tensors
         ix = coords.long()
         g = grad_out[ix[:, 0], :, ix[:, 1], ix[:, 2], ix[:, 3]]
-        return g.contiguous(), None, None, None
+        return g.contiguous(), None, None, None, None
 
 
 class SparseConvTensor:
@@ -209,7 +218,11 @@ class SparseConvTensor:
         if not f.is_cuda:
             raise RuntimeError("SparseConvTensor.dense() runs on the GPU only (no CPU fallback)")
         shape3 = self._shape3()
-        out = _DenseFunction.apply(f, self._coords4(), self.batch_size, tuple(shape3))
+        cache = self._index_holder[0]
+        sorted_index = None
+        if cache is not None and cache.valid_for(self.indices) and cache.perm is None and len(self.spatial_shape) == 3:
+            sorted_index = cache.index          # seeded by a strided conv: row i is the site of rank i
+        out = _DenseFunction.apply(f, self._coords4(), self.batch_size, tuple(shape3), sorted_index)
         if len(self.spatial_shape) == 2:
             out = out[:, :, 0]
         if not channels_first:

@@ -285,6 +285,27 @@ def test_dense_sorted_rows_exact(dtype, cuda_device):
                                         _lib.stream()) == -4
 
 
+def test_module_dense_after_strided_conv_uses_sorted_form(cuda_device):
+    """SparseConv3d output (.dense() finds the seeded site index, rows in key order -> pvx_sparse_to_dense_sorted) == the same
+    tensor densified through the coordinate scatter, and gradients still flow to the features"""
+    rng = np.random.default_rng(31)
+    batch, shape = 2, [5, 40, 64]
+    coords = clustered_sites(rng, batch, shape, 5000)
+    feat = rng.normal(size=(coords.shape[0], 16)).astype(np.float32)
+    x = make_tensor(coords, feat, shape, batch, cuda_device, torch.bfloat16)
+    conv = spconv.SparseConv3d(16, 32, 3, stride=2, padding=1, bias=False).to(cuda_device).to(torch.bfloat16)
+    y = conv(x)
+    cache = y._index_holder[0]
+    assert cache is not None and cache.perm is None and y.spatial_shape[2] % 4 == 0
+    d_sorted = y.dense()
+    plain = spconv.SparseConvTensor(y.features, y.indices, y.spatial_shape, batch)      # no seeded index: scatter form
+    d_plain = plain.dense()
+    assert torch.equal(d_sorted.view(torch.int16), d_plain.view(torch.int16)) and int((d_sorted != 0).sum()) > 0
+    f = y.features.detach().clone().requires_grad_(True)
+    y.replace_feature(f).dense().float().sum().backward()
+    assert torch.equal(f.grad, torch.ones_like(f))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_epilogue_and_device_counts(dtype, cuda_device):
     """pvx_sparse_conv_fwd with folded BN (scale, shift), residual and ReLU, driven by a DEVICE row count smaller
