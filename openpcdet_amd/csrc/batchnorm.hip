@@ -254,6 +254,7 @@ int fwd_impl(const void* x, int n, int c, const float* gamma, const float* beta,
                        save_invstd, w.scale, w.shift);
     PVX_CHECK_LAUNCH();
     const long long chunks = (long long)n * c / Vec<E>::N;
+    if (chunks == 0) return PVX_OK;                         // SyncBatchNorm rank without rows: statistics only
     const long long gb = PVX_CDIV(chunks, (long long)kBlk);
     hipLaunchKernelGGL((bn_apply_kernel<E>), dim3((unsigned)(gb > 65536 ? 65536 : gb)), dim3(kBlk), 0, st, (const E*)x, (const E*)residual,
                        chunks, c, save_mean, w.scale, w.shift, relu, (E*)y);
@@ -282,6 +283,7 @@ int bwd_impl(const void* dy, const void* x, const void* y, int n, int c, const f
                        phase == 2 ? nullptr : dbeta, w.scale, w.shift, w.k_mgx);
     PVX_CHECK_LAUNCH();
     const long long chunks = (long long)n * c / Vec<E>::N;
+    if (chunks == 0) return PVX_OK;
     const long long gb = PVX_CDIV(chunks, (long long)kBlk);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<E>), dim3((unsigned)(gb > 65536 ? 65536 : gb)), dim3(kBlk), 0, st, (const E*)dy, (const E*)x,
                        (const E*)y, chunks, c, mean, invstd, w.scale, w.shift, w.k_mgx, relu, (E*)dx, (E*)dres);
@@ -304,8 +306,10 @@ extern "C" int pvx_bn_act_fwd_sync(const void* x, int n, int c, int dtype, const
                                    float momentum, float* running_mean, float* running_var, const void* residual, int relu, void* y,
                                    float* save_mean, float* save_invstd, double* sums, long long n_total, int phase, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    if (n <= 0 || !x || phase < 0 || phase > 2 || !(eps >= 0.f)) return PVX_ERR_INVALID;
-    if (phase != 1 && (!y || !save_mean || !save_invstd)) return PVX_ERR_INVALID;
+    // a rank of a SyncBatchNorm group may hold no rows (phases 1 / 2): it contributes zero sums and applies nothing, but it must
+    // issue the same collective as its peers; the single-process form (phase 0) needs rows
+    if (n < 0 || (n == 0 && phase == 0) || (n > 0 && !x) || phase < 0 || phase > 2 || !(eps >= 0.f)) return PVX_ERR_INVALID;
+    if (phase != 1 && ((n > 0 && !y) || !save_mean || !save_invstd)) return PVX_ERR_INVALID;
     if (phase != 0 && !sums) return PVX_ERR_INVALID;        // n_total <= 0 in phase 2: read the row count from sums[2 c]
     if (!pvx_bn_act_supported(c, dtype)) return PVX_ERR_RANGE;
     PvxCarver cv(workspace, workspace_bytes);
@@ -328,8 +332,9 @@ extern "C" int pvx_bn_act_bwd_sync(const void* dy, const void* x, const void* y,
                                    const float* save_mean, const float* save_invstd, int relu, void* dx, void* dres, float* dgamma,
                                    float* dbeta, double* sums, long long n_total, int phase, void* workspace, size_t workspace_bytes,
                                    void* stream) {
-    if (n <= 0 || !dy || !x || !save_mean || !save_invstd || (relu && !y) || phase < 0 || phase > 2) return PVX_ERR_INVALID;
-    if (phase != 1 && !dx) return PVX_ERR_INVALID;
+    if (n < 0 || (n == 0 && phase == 0) || (n > 0 && (!dy || !x || (relu && !y))) || !save_mean || !save_invstd || phase < 0 || phase > 2)
+        return PVX_ERR_INVALID;
+    if (phase != 1 && n > 0 && !dx) return PVX_ERR_INVALID;
     if (phase != 0 && !sums) return PVX_ERR_INVALID;        // n_total <= 0 in phase 2: read the row count from sums[2 c]
     if (!pvx_bn_act_supported(c, dtype)) return PVX_ERR_RANGE;
     PvxCarver cv(workspace, workspace_bytes);

@@ -766,8 +766,11 @@ extern "C" int pvx_sparse_to_dense_sorted(const void* feat, const void* index, i
     int split = split_env > 0 ? split_env : 4;
     while (split > 1 && (c / 2) % split) split >>= 1;
     const size_t per_line = (size_t)s.w * (1 + ((c / 2 / split) | 1)) * sizeof(unsigned);
-    if (per_line > 64 * 1024) return PVX_ERR_RANGE;
-    int ylines = (int)(64 * 1024 / per_line);
+    // the kernel also holds 8 bytes of static LDS (r_lo, r_hi): budget 64 KiB minus 16, so that a line of exactly 32 or 64 KiB
+    // is refused here (PVX_ERR_RANGE: callers fall back to the scatter form) instead of failing at launch
+    constexpr size_t kLdsBudget = 64 * 1024 - 16;
+    if (per_line > kLdsBudget) return PVX_ERR_RANGE;
+    int ylines = (int)(kLdsBudget / per_line);
     if (ylines > 2) ylines = 2;
     if (lines_env > 0 && lines_env < ylines) ylines = lines_env;
     if (ylines > s.h) ylines = s.h;

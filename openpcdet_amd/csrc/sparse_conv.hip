@@ -25,12 +25,11 @@
 // Generic path (fp32, or channel counts the MFMA tiling does not cover): one thread per (site, cout), fp32 math.
 #include "pvx_common.h"
 #include <stdlib.h>
+#include "sparse_conv_st.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "conv_mfma32.h"
 
 constexpr int kBlk = 256;
 
@@ -285,7 +284,6 @@ constexpr int kResidentBytes = 112 * 1024;
 // diagnostic build only (PVX_ABLATE bit 32): per-workgroup cycle sums of the tile phases, read back by pvx_debug_conv_stamps
 __device__ unsigned long long g_conv_stamps[1024 * 8];
 
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <int CIN, int COUT, int NT> struct Plan {
     typedef Tiling<CIN, COUT> TL;
@@ -822,6 +820,11 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
     if (!prepared_weight || !nbr || !out || (n_in > 0 && !feat_in)) return PVX_ERR_INVALID;
     if ((long long)n_out * cout > 0x7fffffff00ll) return PVX_ERR_RANGE;
     hipStream_t st = (hipStream_t)stream;
+    if (tilebook && tilebook_rcap > 0 && tilebook_rcap == pvx_st_rcap(cin, cout, kvol, dtype)) {      // super-tile form (sparse_conv_st.hip)
+        const int rc_st = pvx_st_launch(feat_in, n_in, cin, prepared_weight, bias, nbr, n_out, n_out_dev, cout, dtype, scale, shift, residual,
+                                        relu, out, tilebook, tilebook_rcap, stream);
+        if (rc_st != PVX_ERR_RANGE) return rc_st;             // PVX_ERR_RANGE: not taken (no input rows, > 2 GiB of features): the forms below
+    }
     if (w32_shape(cin, cout, kvol, dtype) && v3_shape(cin, cout, kvol, dtype)) {
         int rcv = PVX_ERR_INVALID;
 #define X(ci, co, ck, rc, nwb, wgs)                                                                                           \
@@ -908,6 +911,8 @@ extern "C" int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, co
 }
 
 extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {
+    const int st_rcap = pvx_st_rcap(cin, cout, kvol, dtype);
+    if (st_rcap > 0) return st_rcap;
     return w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) ? tilebook_rcap_of(cin, cout, kvol, dtype) : 0;
 }
 

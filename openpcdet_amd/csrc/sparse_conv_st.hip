@@ -1,0 +1,115 @@
+// SUPER-TILE form of the slab sparse-conv kernel (round 3): the submanifold 3 x 3 x 3 layers whose nine offsets of weights per dz group
+// fit in LDS beside the row window but whose 27 do not (64 -> 64: 72 KiB per group, 216 KiB in all).
+//
+// Same arithmetic as sparse_conv_slab_kernel (sparse_conv_slab.h) -- rows of the input in key order, the neighbours of 256 consecutive
+// output sites at one dz staged in LDS as one window of consecutive rows, MFMA operands read from there, offsets visited in k order,
+// so the sums are bit-identical -- but a different walk, aimed at what that kernel measured as its cost (profiles/r03_conv_st.txt):
+//   * per 256-site tile it read 27 KiB of rulebook and reduced it (min / max per group) before the first MFMA, then loaded
+//     72 KiB of weights + a window per dz group: ~18 us per tile of which ~6 are MFMAs, the rest exposed load -> LDS -> barrier chains,
+//     and 216 KiB of weights came through L2 for every tile.
+//   * here a workgroup owns a CONTIGUOUS run of tiles and walks it in super-tiles of NS tiles, dz-major: group g's weights go to LDS
+//     once per super-tile and serve NS tiles (accumulators of all NS tiles stay in registers), so weight traffic per site drops NS-fold;
+//   * everything a phase (tile, dz group) needs -- its window rows, its 4.5 KiB of tile-book codes, and the weights when the group
+//     changes -- is requested into registers at the START of the previous phase and written to LDS at the start of its own: the
+//     L2 / HBM round trip runs under ~2 us of MFMAs instead of in front of them, across tile and super-tile boundaries;
+//   * window spans come from the tile book's meta words (tilebook_layout.h) by scalar loads one super-tile ahead: no reduction, no
+//     rulebook read (only lanes whose neighbour lies outside the window read its int32 entry, as in sparse_conv_slab_tb_kernel).
+#include "pvx_common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include "tilebook_layout.h"
+#include "sparse_conv_st.h"
+
+namespace {
+
+#include "conv_mfma32.h"
+
+__device__ __forceinline__ int live_rows(int n, const int* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const int v = *n_dev;
+    return v < n ? v : n;
+}
+
+#ifdef PVX_ST_STAMPS
+// diagnostic build only (tools/st_stamps.py): per (workgroup, wave) cycle sums of the phase segments
+__device__ unsigned long long g_st_stamps[256 * 8 * 8];
+#define ST_STAMP(seg) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_sum[seg] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define ST_STAMP(seg) do { } while (0)
+#endif
+
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef const u32x8 __attribute__((address_space(4)))* MetaPtr;
+
+#include "sparse_conv_ws.h"
+
+int num_cus8() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return (cus + 7) / 8 * 8;
+}
+
+// Shapes with a super-tile form: X(cin, cout, window rows, tiles per super-tile of the wave-specialised kernel)
+#define PVX_ST_SHAPES(X) X(64, 64, 640, 1)
+
+int st_mode() {
+    static int v = -1;
+    // PVX_CONV_ST (A/B switch): 0 = the round-2 slab forms, 1 = the wave-specialised super-tile kernel (default)
+    if (v < 0) { const char* e = getenv("PVX_CONV_ST"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+template <typename E, int CIN, int COUT, int RCAP, int NS>
+int launch_st(const void* feat, int n_in, const void* w, const int* nbr, const void* book, int n_out, const int* n_out_dev,
+              const float* bias, const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
+    const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
+    const unsigned long long out_bytes = (unsigned long long)n_out * COUT * sizeof(E);
+    if (feat_bytes >= 0x80000000ull || out_bytes >= 0x80000000ull || n_in <= 0) return PVX_ERR_RANGE;     // 32-bit buffer offsets
+    int grid = num_cus8();
+    const int tiles = PVX_CDIV(n_out, 256);
+    if (grid > tiles) grid = (tiles + 7) / 8 * 8;
+    hipLaunchKernelGGL((sparse_conv_slab_ws_kernel<E, CIN, COUT, RCAP, NS>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
+                       (unsigned)feat_bytes, (const u32x4*)w, nbr, (const u32x4*)book, n_out, n_out_dev, bias, scale, shift,
+                       (const E*)residual, (unsigned)out_bytes, relu, (E*)out);
+    PVX_CHECK_LAUNCH();
+    return PVX_OK;
+}
+
+}  // namespace
+
+#ifdef PVX_ST_STAMPS
+extern "C" int pvx_debug_st_stamps(unsigned long long* host_out, int n_words) {
+    if (!host_out || n_words <= 0 || n_words > 256 * 8 * 8) return PVX_ERR_INVALID;
+    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_st_stamps), (size_t)n_words * sizeof(unsigned long long)));
+    return PVX_OK;
+}
+#endif
+
+int pvx_st_rcap(int cin, int cout, int kvol, int dtype) {
+    if (kvol != 27 || (dtype != PVX_BF16 && dtype != PVX_F16) || st_mode() == 0) return 0;
+#define X(ci, co, rc, ns) if (cin == ci && cout == co) return rc;
+    PVX_ST_SHAPES(X)
+#undef X
+    return 0;
+}
+
+int pvx_st_launch(const void* feat, int n_in, int cin, const void* prepared_weight, const float* bias, const int* nbr, int n_out,
+                  const int* n_out_dev, int cout, int dtype, const float* scale, const float* shift, const void* residual, int relu,
+                  void* out, const void* tilebook, int tilebook_rcap, void* stream) {
+    if (!tilebook || tilebook_rcap <= 0 || tilebook_rcap != pvx_st_rcap(cin, cout, 27, dtype)) return PVX_ERR_RANGE;
+    hipStream_t st = (hipStream_t)stream;
+#define X(ci, co, rc, ns)                                                                                                       \
+    if (cin == ci && cout == co) {                                                                                              \
+        if (dtype == PVX_BF16)                                                                                                  \
+            return launch_st<__bf16, ci, co, rc, ns>(feat, n_in, prepared_weight, nbr, tilebook, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
+        return launch_st<_Float16, ci, co, rc, ns>(feat, n_in, prepared_weight, nbr, tilebook, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st);   \
+    }
+    PVX_ST_SHAPES(X)
+#undef X
+    return PVX_ERR_RANGE;
+}

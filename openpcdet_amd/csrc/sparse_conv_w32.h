@@ -15,28 +15,7 @@
 // XCD-aware persistent tiles) is the one described above sparse_conv_mfma2_kernel.
 #pragma once
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-template <typename E> struct Mfma32;
-template <> struct Mfma32<__bf16> {
-    static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mfma32<_Float16> {
-    static __device__ __forceinline__ f32x16 run(uint4 a, uint4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-
-template <int CIN, int COUT> struct Tiling32 {
-    static_assert(CIN % 16 == 0, "CIN must be a multiple of 16");
-    static_assert(COUT % 16 == 0, "COUT must be a multiple of 16");
-    static constexpr int S = CIN / 16;                 // K-steps per kernel offset
-    static constexpr int T = (COUT + 31) / 32;         // cout tiles (a 16-cout layer half-fills its tile)
-    static constexpr int GROUP_U4 = S * T * 64;        // uint4 per kernel offset: S * T KiB
-    static constexpr int GROUP_BYTES = GROUP_U4 * 16;
-};
+#include "conv_mfma32.h"
 
 // element j of lane l of fragment (offset k, step s, cout tile t) <- raw weight [cout][k][cin]
 template <int CIN, int COUT>

@@ -128,7 +128,7 @@ class HotPathEngine:
 
     # layers that share a rulebook with enough launches to pay for its book (55 us): the five 16 -> 16 layers (bound by rulebook
     # bytes) and the four 32 -> 32 layers (the rolling kernel form needs the book's window spans a tile ahead)
-    TILEBOOK_SHAPES = {(16, 16), (32, 32)}
+    TILEBOOK_SHAPES = {(16, 16), (32, 32), (64, 64)}
 
     def _wants_tilebook(self, cin, cout):
         if self.tilebook_mode == "0":
@@ -322,7 +322,7 @@ class HotPathEngine:
             # zero-fill + scatter, the A/B switch and the fall-back for shapes the line form does not take)
             w, words = cur.shape3[2], self.out_channels // 2
             lines_ok = (os.environ.get("PVX_ENGINE_DENSE_LINES", "1") != "0" and self.dtype in (torch.bfloat16, torch.float16)
-                        and self.out_channels % 2 == 0 and w % 4 == 0 and (w + w * ((words // (4 if words % 4 == 0 else 1)) | 1)) * 4 <= 64 * 1024
+                        and self.out_channels % 2 == 0 and w % 4 == 0 and (w + w * ((words // (4 if words % 4 == 0 else 2 if words % 2 == 0 else 1)) | 1)) * 4 <= 64 * 1024 - 16
                         and len(self.levels) > 1)
             if lines_ok:
                 al = (_lib.ptr(cur_feat), _lib.ptr(cur.index), cur.cap, _lib.ptr(cur.n_dev), self.out_channels, self.code, B,

@@ -127,7 +127,11 @@ def _sync_group(bn):
 
 def fusable(bn, x):
     if type(bn) is nn.SyncBatchNorm:
-        return (_ENABLED and bn.training and bn.momentum is not None and x.is_cuda and x.dim() == 2 and x.shape[0] > 1
+        # decided from facts every rank of the group shares (module, mode, dtype, channels, group) and never from this rank's row
+        # count: the fused path issues ONE all-reduce where torch's SyncBatchNorm issues an all-gather, so two ranks that chose
+        # differently (a frame with a single active row at some level, PartA2's fake_sparse_idx) would hang or mix buffers.
+        # The kernels take n == 1, and n == 0 as "zero sums, nothing to apply".
+        return (_ENABLED and bn.training and bn.momentum is not None and x.is_cuda and x.dim() == 2
                 and x.dtype in _lib.DTYPE_CODE and _sync_group(bn) is not None
                 and bool(_lib.lib().pvx_bn_act_supported(x.shape[1], _lib.DTYPE_CODE[x.dtype])))
     return (_ENABLED and type(bn) is nn.BatchNorm1d and bn.training and bn.momentum is not None and x.is_cuda and x.dim() == 2

@@ -76,7 +76,7 @@ def test_bn_act_fallbacks_and_sequential(cuda_device):
     x32 = torch.randn(500, 32, device=cuda_device)
     assert norm.fusable(bn32.train(), x32) and not norm.fusable(bn32.eval(), x32) and not norm.fusable(bn32.train(), x32.cpu())
     sync = torch.nn.SyncBatchNorm(32).to(cuda_device).train()
-    assert not norm.fusable(sync, x32)
+    assert not norm.fusable(sync, x32)                            # no process group here: torch's SyncBatchNorm does not synchronise either
     # SparseSequential(conv, bn, relu): same features as conv -> torch bn -> relu
     seq = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="k"), torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01),
                                   torch.nn.ReLU()).to(cuda_device).train()
@@ -93,7 +93,7 @@ def test_bn_act_fallbacks_and_sequential(cuda_device):
     assert int(seq[1].num_batches_tracked) == 1                   # the explicit seq[0](xt) call above does not touch the BatchNorm
 
 
-def _sync_worker(rank, world, port, out):
+def _sync_worker(rank, world, port, out, cut=5000):
     """one of two ranks on the same GPU (gloo carries the CUDA tensors of the all-reduce): each normalises its half of the rows with
     statistics over both halves"""
     import os
@@ -107,7 +107,7 @@ def _sync_worker(rank, world, port, out):
         x = (torch.randn(n, c) * 1.3 + 0.4).to(dev)
         res = torch.randn(n, c).to(dev)
         up = torch.randn(n, c).to(dev)
-        lo, hi = (0, 5000) if rank == 0 else (5000, n)          # unequal shares
+        lo, hi = (0, cut) if rank == 0 else (cut, n)            # unequal shares; cut = 1 / 0: a rank with one row / without rows
         bn = torch.nn.SyncBatchNorm(c, eps=1e-3, momentum=0.01).to(dev).train()
         with torch.no_grad():
             bn.weight.copy_(torch.linspace(0.5, 1.5, c))
@@ -124,9 +124,11 @@ def _sync_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_sync_bn_two_ranks(cuda_device):
+@pytest.mark.parametrize("cut", [5000, 1, 0])
+def test_sync_bn_two_ranks(cuda_device, cut):
     """SyncBatchNorm through the fused kernels at world size 2 == BatchNorm over the concatenated rows (float64 CPU reference);
-    weight / bias gradients are per-rank sums whose total is the reference's"""
+    weight / bias gradients are per-rank sums whose total is the reference's.  cut = 1 / 0: rank 0 holds one row / no row and must
+    still take the fused path (the same single all-reduce as its peer), ADVICE round 2"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -135,7 +137,7 @@ def test_sync_bn_two_ranks(cuda_device):
     s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_sync_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_sync_worker, args=(2, port, out, cut), nprocs=2, join=True)
     torch.manual_seed(11)
     c, n = 32, 9001
     x = torch.randn(n, c) * 1.3 + 0.4
