@@ -54,12 +54,12 @@ int num_cus8() {
     return (cus + 7) / 8 * 8;
 }
 
-// Shapes with a super-tile form: X(cin, cout, window rows, tiles per super-tile of the wave-specialised kernel)
+// Shapes with this form: X(cin, cout, window rows, tiles per super-tile)
 #define PVX_ST_SHAPES(X) X(64, 64, 640, 1)
 
 int st_mode() {
     static int v = -1;
-    // PVX_CONV_ST (A/B switch): 0 = the round-2 slab forms, 1 = the wave-specialised super-tile kernel (default)
+    // PVX_CONV_ST=0 (A/B switch): the round-2 slab forms
     if (v < 0) { const char* e = getenv("PVX_CONV_ST"); v = e ? atoi(e) : 1; }
     return v;
 }
