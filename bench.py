@@ -68,40 +68,54 @@ def make_inputs(cfg, rank, pool, dev):
     return frames, torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev), torch.from_numpy(counts).to(dev)
 
 
-def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts, single_thread_frames=0):
-    """the oracle chain on host cores: one untimed warm-up frame, then n_frames timed frames; frames/s from the MEDIAN frame time
-    -> (frames/s, threads, description, frames/s on one thread or None)"""
+def cpu_baseline(cfg, net_cpu, n_frames, boxes, scores, counts, warmups=3, single_thread_frames=1):
+    """The oracle chain on the host cores, BASELINE.md section 3: `warmups` untimed frames, then n_frames timed full frames (the GPU run's
+    own synthetic frames and seeds), frames/s from the MEDIAN frame time, per-stage medians, on all threads; then the same chain on ONE
+    thread for single_thread_frames frames (a full frame takes ~35 s there, so that sample is bounded to what the default run can afford).
+    -> dict for the JSON line"""
     from oracle import chain, loader
     threads = int(loader.oracle().orc_num_threads())
 
-    def one(i):
+    def one(i, stages=None):
         pts = synth.config_cloud(WORKLOAD, 3 + i)
         t0 = time.perf_counter()
-        chain.backbone_chain(net_cpu, [pts], cfg)
-        chain.heads_nms(boxes[i], scores[i], counts[i], NMS_THRESH, NMS_POST)
-        return time.perf_counter() - t0
+        tm = {}
+        chain.backbone_chain(net_cpu, [pts], cfg, timings=tm)
+        t1 = time.perf_counter()
+        chain.heads_nms(boxes[i % len(boxes)], scores[i % len(boxes)], counts[i % len(boxes)], NMS_THRESH, NMS_POST)
+        t2 = time.perf_counter()
+        if stages is not None:
+            tm["nms"] = t2 - t1
+            stages.append(tm)
+        return t2 - t0
 
-    one(0)
-    ts = sorted(one(i) for i in range(n_frames))
+    for i in range(warmups):
+        one(i)
+    stages = []
+    ts = sorted(one(warmups + i, stages) for i in range(n_frames))
     med = ts[len(ts) // 2]
-    single = None
+    stage_ms = {k: round(sorted(st[k] for st in stages)[len(stages) // 2] * 1e3, 2) for k in stages[0]} if stages else {}
+    out = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(),
+           "stage_ms_median": stage_ms,
+           "sample": "%d warm-ups + %d timed full frames (300k points each), median frame time, fp32, all stages; convs on %d OpenMP "
+                     "threads, voxelizer / rulebook / NMS single-threaded (BASELINE.md section 3)" % (warmups, n_frames, threads)}
     if single_thread_frames > 0:
         prev = torch.get_num_threads()
         loader.oracle().orc_set_num_threads(1)
         torch.set_num_threads(1)
         t1 = sorted(one(i) for i in range(single_thread_frames))
-        single = 1.0 / t1[len(t1) // 2]
+        out["value_1_thread"] = round(1.0 / t1[len(t1) // 2], 4)
+        out["sample_1_thread"] = "%d timed full frame(s), no warm-up (a frame takes ~35 s on one thread)" % single_thread_frames
         torch.set_num_threads(prev)
         loader.oracle().orc_set_num_threads(threads)
-    return 1.0 / med, threads, "1 warm-up + %d timed full frames (300k points each), median frame time, fp32, all stages; convs on %d " \
-        "OpenMP threads, voxelizer / rulebook / NMS single-threaded" % (n_frames, threads), single
+    return out
 
 
 # which HIP kernel a (cin, cout, kernel volume) layer of this backbone launches (csrc/sparse_conv_slab.h PVX_SLAB_SHAPES,
 # csrc/sparse_conv_w32.h); the names are the ones rocprofv3 --kernel-trace --stats prints
 def conv_kernel_name(cin, cout, kvol):
-    if os.environ.get("PVX_CONV_V3", "0") != "0" and kvol == 27 and (cin, cout) in ((64, 64), (128, 128), (64, 128)):
-        return "sparse_conv_v3_kernel<bf16,%d,%d>" % (cin, cout)
+    if kvol == 27 and (cin, cout) == (64, 64) and os.environ.get("PVX_CONV_ST", "1") != "0" and os.environ.get("PVX_ENGINE_TILEBOOK", "1") == "1":
+        return "sparse_conv_slab_ws_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in engine.HotPathEngine.TILEBOOK_SHAPES and os.environ.get("PVX_ENGINE_TILEBOOK", "1") == "1":
         if (cin, cout) == (32, 32) and os.environ.get("PVX_CONV_ROLL", "1") != "0":
             return "sparse_conv_slab_roll_kernel<bf16,%d,%d>" % (cin, cout)
@@ -112,6 +126,43 @@ def conv_kernel_name(cin, cout, kvol):
     if kvol == 27 and (cin, cout) in ((64, 128), (128, 64), (128, 128)):
         return "sparse_conv_slab_stream_kernel<bf16,%d,%d>" % (cin, cout)
     return "sparse_conv_w32_kernel<bf16,%d,%d>" % (cin, cout)
+
+
+class Watchdog:
+    """Host-side guard of the timed loop: a daemon thread that, when nothing has ticked for `timeout_s`, prints every stream's last
+    COMPLETED step (events recorded at the end of each step's enqueues, queried without blocking) and ends the process with a fresh
+    exit (os._exit, never a re-exec) -- so a stalled schedule costs seconds and names the stream that stopped, instead of sitting
+    until the harness's limit (round 2's high-priority-geometry run did that: DESIGN.md section 7c)."""
+
+    def __init__(self, timeout_s):
+        import threading
+        self.timeout_s, self.last, self.label = timeout_s, time.monotonic(), "start"
+        self.marks = {}                                        # stream name -> [(step, event)]
+        self.done = False
+        if timeout_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def tick(self, label):
+        self.last, self.label = time.monotonic(), label
+
+    def mark(self, name, stream, step):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        lst = self.marks.setdefault(name, [])
+        lst.append((step, ev))
+        del lst[:-64]
+
+    def _run(self):
+        while not self.done:
+            time.sleep(1.0)
+            if time.monotonic() - self.last > self.timeout_s:
+                state = {}
+                for name, lst in self.marks.items():
+                    finished = [st for st, ev in lst if ev.query()]
+                    state[name] = {"last_completed_step": max(finished) if finished else None, "last_enqueued_step": lst[-1][0] if lst else None}
+                print(json.dumps({"watchdog": "no progress for %.0f s after '%s'" % (self.timeout_s, self.label), "streams": state}),
+                      file=sys.stderr, flush=True)
+                os._exit(3)
 
 
 def main():
@@ -126,7 +177,11 @@ def main():
                     help="start the next batch's voxelization after this many conv launches of the current batch (0 = at once; 6..7 measured "
                          "best for this backbone with the in-kernel NMS front end and the rolling 32->32 kernel: profiles/r02_schedule_sweep.txt)")
     ap.add_argument("--cap-factor", type=float, default=2.0, help="row capacity of a strided conv's output relative to its input's")
-    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames per GPU")
+    ap.add_argument("--pool", type=int, default=0, help="distinct synthetic frames per GPU (0 = 2 x batch: consecutive steps see different frames)")
+    ap.add_argument("--geo-priority", default="normal", choices=("normal", "high"),
+                    help="priority of the geometry stream (diagnostic: 'high' is the setting that hung in round 2; run it only under the watchdog)")
+    ap.add_argument("--watchdog-s", type=float, default=60.0, help="exit non-zero, with every stream's last completed step, after this many "
+                    "seconds without progress (0 = off)")
     ap.add_argument("--nms-stream", default="own", choices=("own", "vox"), help="stream of the NMS launches: its own, or the voxelizer's")
     ap.add_argument("--nms-first", action="store_true", help="issue the NMS launches before the plan's (diagnostic)")
     ap.add_argument("--nms-after", type=int, default=14, help="hold the NMS back until this conv layer of the batch has been reached (0 = do not)")
@@ -136,8 +191,8 @@ def main():
     ap.add_argument("--flat-priority", action="store_true", help="do not raise the priority of the conv stream (A/B switch)")
     ap.add_argument("--no-pipeline", action="store_true", help="one plan: geometry overlaps only the convs of its own batch")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: no geometry / conv / NMS overlap (A/B switch)")
-    ap.add_argument("--cpu-frames", type=int, default=5, help="timed frames of the CPU-oracle baseline after one warm-up frame (0 = skip); ~15 s of CPU work")
-    ap.add_argument("--cpu-single-frames", type=int, default=0, help="also time this many frames with the oracle on ONE thread (~35 s each; profiles/ only)")
+    ap.add_argument("--cpu-frames", type=int, default=20, help="timed frames of the CPU-oracle baseline after 3 warm-up frames (0 = skip); ~55 s of CPU work")
+    ap.add_argument("--cpu-single-frames", type=int, default=1, help="also time this many frames with the oracle on ONE thread (~35 s each)")
     ap.add_argument("--profile-passes", type=int, default=5)
     args = ap.parse_args()
 
@@ -151,7 +206,8 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     cfg = synth.CONFIGS[WORKLOAD]
-    B, P = args.batch, max(args.pool, args.batch)
+    B = args.batch
+    P = max(args.pool if args.pool > 0 else 2 * B, B)
     net = build_model(cfg, dev)
     eng = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
                                dtype=torch.bfloat16, device=dev, level_capacity_factor=args.cap_factor)
@@ -161,6 +217,13 @@ def main():
     if pipelined:   # two plans alternate so that the geometry of batch i+1 runs beside the convolutions of batch i
         eng2 = engine.HotPathEngine(net, B, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], cfg["n_points"],
                                     dtype=torch.bfloat16, device=dev, level_capacity_factor=args.cap_factor)
+    lo, hi = torch.cuda.Stream.priority_range()
+    if pipelined:
+        # FOUR streams by construction -- convs, geometry (both plans: batch i + 1's rulebooks follow batch i's anyway), voxelize-ahead,
+        # NMS -- so that no two of them share one of the process's four hardware queues (GPU_MAX_HW_QUEUES); round 2 ran six
+        geo_shared = torch.cuda.Stream(device=dev, priority=hi if args.geo_priority == "high" else 0)
+        eng.use_geometry_stream(geo_shared)
+        eng2.use_geometry_stream(geo_shared)
     frames, boxes, scores, counts = make_inputs(cfg, rank, P, dev)
     # static NMS inputs of one step (what the dense head would have decoded for the B frames)
     s_boxes = torch.zeros((B * HEADS, BOXES_PER_HEAD, 9), device=dev)
@@ -237,6 +300,7 @@ def main():
 
     vox_ahead = pipelined and not args.no_vox_ahead
     vox_stream = torch.cuda.Stream(device=dev) if vox_ahead else None
+    wd = Watchdog(args.watchdog_s)
 
     nms_on = vox_stream if (vox_ahead and args.nms_stream == "vox") else nms_stream
 
@@ -271,6 +335,10 @@ def main():
             if not args.nms_first:
                 run_nms()
             cur.wait_stream(nms_on)
+            for nm, st_ in (("conv", cur), ("geometry", plan.geometry_stream()), ("voxelize", vox_stream), ("nms", nms_on)):
+                if st_ is not None:
+                    wd.mark(nm, st_, i)
+            wd.tick("step %d enqueued" % i)
             return
         load(i)
         if graph is not None:
@@ -279,7 +347,6 @@ def main():
             hot_path()
 
     # the convolutions are the critical path: they get the high-priority stream, geometry and NMS fill in around them
-    lo, hi = torch.cuda.Stream.priority_range()
     conv_stream = torch.cuda.Stream(device=dev, priority=hi) if (pipelined and not args.flat_priority) else torch.cuda.current_stream(dev)
     conv_stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(conv_stream):
@@ -295,7 +362,19 @@ def main():
             step(i)
             host_ms.append((time.perf_counter() - h0) * 1e3)
 
+        wd.tick("warm-up enqueued")
         elapsed = pdist.timed_steps(timed_step, args.steps, device=dev, first=args.warmup)
+        wd.tick("timed region done")
+        # the conv launches' durations INSIDE this schedule (beside the geometry / NMS streams): six more steps with an event pair
+        # around every conv launch; outside the timed region
+        ov_events = []
+        if pipelined:
+            eng.conv_events, eng2.conv_events = ov_events, ov_events
+            for i in range(args.warmup + args.steps, args.warmup + args.steps + 6):
+                step(i)
+            torch.cuda.synchronize()
+            eng.conv_events, eng2.conv_events = None, None
+            wd.tick("overlapped conv timing done")
         note("host enqueue ms per step inside the timed region: first %s ... last %s" % (
             ["%.2f" % v for v in host_ms[:4]], ["%.2f" % v for v in host_ms[-4:]]))
         if os.environ.get("BENCH_HOSTTIME"):      # how long the HOST spends enqueuing one step (must stay well below the step)
@@ -307,6 +386,7 @@ def main():
             torch.cuda.synchronize()
             note("host enqueue ms per step: %s" % ["%.2f" % v for v in ht])
     torch.cuda.current_stream(dev).wait_stream(conv_stream)
+    wd.done = True
     note("stream priority range %s" % ((lo, hi),))
     note("timed region done: %.3f s" % elapsed)
     assert not eng.overflowed() and (eng2 is None or not eng2.overflowed()), "a level overflowed its row capacity"
@@ -316,7 +396,7 @@ def main():
     if rank == 0:
         # ---- the last timed step's results against a serial, single-stream re-run of the same batch on the same kernels: the
         #      overlapped schedule (4 streams, 2 plans, or the graph replay) must not change a bit ----
-        i_last = args.warmup + args.steps - 1
+        i_last = args.warmup + args.steps - 1 + (6 if pipelined else 0)
         plan_last = (eng if i_last % 2 == 0 else eng2) if pipelined else eng
         bev_last, sel_last, num_last = plan_last.dense.clone(), result["sel"].clone(), result["num"].clone()
         load(i_last)
@@ -372,16 +452,19 @@ def main():
             n_in = min(int(rec["level_in"].n_dev.item()), rec["level_in"].cap)
             byts = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 * (2 if rec["residual"] else 1) + rec["kvol"] * n_rows * 4 + \
                 rec["kvol"] * rec["cin"] * rec["cout"] * 2
+            # SURVEY.md 8d's compulsory bytes: features in + features out + weights, no rulebook, no residual
+            comp = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 + rec["kvol"] * rec["cin"] * rec["cout"] * 2
             us = sum(a.elapsed_time(b) for a, b in ev[lname]) / passes * 1e3
-            g = groups.setdefault(kname, dict(kernel=kname, launches_per_step=0, flops=0, bytes=0, us=0.0))
+            g = groups.setdefault(kname, dict(kernel=kname, launches_per_step=0, flops=0, bytes=0, comp=0, us=0.0))
             g["launches_per_step"] += 1
             g["flops"] += f
             g["bytes"] += byts
+            g["comp"] += comp
             g["us"] += us
         # HBM bytes per launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs, FETCH_SIZE doubled as the gfx950 note prescribes: tools/pmc_traffic.py); null when the file is absent
         traffic, traffic_src, pmc_by_kernel = None, None, {}
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", "%s_pmc_traffic_b%d.json" % (tag, B))
             if os.path.exists(tpath):
                 rows_t = [r for r in json.load(open(tpath)) if r["kernel"].startswith("sparse_conv")]
@@ -395,7 +478,7 @@ def main():
 
         def pmc_for(kname):     # tools/pmc_traffic.py keys: sparse_conv_slab<cin=64,cout=64> / sparse_conv_w32<cin=..,cout=..>
             ch = kname.split("<")[1].rstrip(">").split(",")[1:]
-            kind = "sparse_conv_slab" if "slab" in kname else ("sparse_conv_v3" if "v3" in kname else "sparse_conv_w32")
+            kind = "sparse_conv_slab" if "slab" in kname else "sparse_conv_w32"
             return pmc_by_kernel.get("%s<cin=%s,cout=%s>" % (kind, ch[0], ch[1]))
 
         per_kernel = []
@@ -404,11 +487,23 @@ def main():
             per_kernel.append({"kernel": g["kernel"], "launches_per_step": n, "flops_per_launch": int(g["flops"] / n),
                                "avg_us": round(g["us"] / n, 1), "tflops": round(g["flops"] / (g["us"] * 1e-6) / 1e12, 1),
                                "frac": round(g["flops"] / (g["us"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 4),
-                               "alg_bytes_per_launch": int(g["bytes"] / n),
-                               "alg_GBps": round(g["bytes"] / (g["us"] * 1e-6) / 1e9), "pmc_bytes_per_launch": pmc_for(g["kernel"])})
+                               "alg_bytes_per_launch": int(g["bytes"] / n), "compulsory_bytes_per_launch": int(g["comp"] / n),
+                               "alg_GBps": round(g["bytes"] / (g["us"] * 1e-6) / 1e9), "pmc_bytes_per_launch": pmc_for(g["kernel"]),
+                               "pmc_over_compulsory": (round(pmc_for(g["kernel"]) / (g["comp"] / n), 2) if pmc_for(g["kernel"]) else None)})
         dom = per_kernel[0]
+        # the same sum from the event pairs recorded INSIDE the overlapped schedule (six steps behind the timed region)
+        frac_ov, conv_ms_ov = None, None
+        if ov_events:
+            conv_ms_ov = sum(a.elapsed_time(b) for _, a, b in ov_events) / 6.0
+            frac_ov = round(flops / (conv_ms_ov * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 5)
+        comp_total = sum(g["comp"] for g in groups.values())
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 5), "frac_overlapped": frac_ov,
+                    "ms_per_step_overlapped": round(conv_ms_ov, 4) if conv_ms_ov else None,
+                    "compulsory_bytes_per_step": int(comp_total),
+                    "sustained_mfma_peak_note": "with every CU issuing v_mfma_f32_32x32x16_bf16 back to back this part holds 1.6 GHz = 1650 TFLOP/s "
+                                                "(tools/probes/mfma_rate.hip); `peak` stays the guide's 2500",
+                    "traffic": traffic, "traffic_source": traffic_src,
                     "basis": "serial: one stream, HIP events around each conv launch of the same plan, %d passes after the timed region; "
                              "frac = sum of algorithmic flops / sum of those durations (all %d conv launches of a step)" % (passes, conv_launches),
                     "kernel": "all sparse-conv launches of a step; dominant: %s" % dom["kernel"],
@@ -429,11 +524,8 @@ def main():
                "rulebook": {"bytes": rule_bytes, "GBps": round(rule_bytes / (rule_ms * 1e-3) / 1e9, 1)}}
         cpu = None
         if args.cpu_frames > 0 and world == 1:     # reported at N = 1 only
-            v, threads, sample, single = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(),
-                                                      counts.cpu().numpy(), args.cpu_single_frames)
-            cpu = {"value": round(v, 4), "unit": "frames/s", "cores": threads, "kind": "port", "sample": sample}
-            if single is not None:
-                cpu["value_1_thread"] = round(single, 4)
+            cpu = cpu_baseline(cfg, net.cpu().float(), args.cpu_frames, boxes.cpu().numpy(), scores.cpu().numpy(), counts.cpu().numpy(),
+                               single_thread_frames=args.cpu_single_frames)
         value = world * B * args.steps / elapsed
         out = {
             "metric": "frames/sec voxelize+sparse backbone+NMS (nuScenes CenterPoint)",
@@ -444,6 +536,7 @@ def main():
                                    "6 heads x 500 boxes NMS @0.2 (BASELINE.json configs[2])",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": "frame-sharded x%d" % world,
                        "hip_graph": graph is not None, "streams": 1 if args.no_overlap else (4 if vox_ahead else 3), "plans_in_flight": 2 if pipelined else 1,
+                       "frame_pool": P,
                        "voxelize_ahead": bool(vox_ahead), "geo_after": args.geo_after, "rows_per_level": rows},
             "roofline": roofline, "hbm_stages": hbm, "cpu_baseline": cpu, "checked": checked,
             "stages": {"voxelize_ms": round(vox_ms, 4), "rulebook_ms": round(rule_ms, 4), "conv_ms": round(conv_ms, 4),

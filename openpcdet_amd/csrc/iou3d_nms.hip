@@ -79,11 +79,14 @@ __global__ __launch_bounds__(kBlock) void bev_paired_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Suppression mask.  grid = (col tiles, row tiles, segments); tiles below the diagonal exit at once.
-// Wave w of the block owns rows 16w..16w+15 of the tile; for every row one ballot over the 64 column lanes
-// is the mask word (bit j <=> iou(row box, column box j) > thresh), exactly the word the reference's thread
-// builds with a 64-step loop (kernel.cu:325-337).  Only columns after the row are set on the diagonal tile
-// (kernel.cu:328-330).
+// Suppression mask.  grid = (col tiles, row tiles, segments); tiles below the diagonal exit at once.  A mask word of row i holds bit j
+// <=> iou(row box i, column box j of the tile) > thresh: the word the reference's thread builds with a 64-step loop
+// (kernel.cu:325-337); on the diagonal tile only columns after the row are set (kernel.cu:328-330).
+//   NORMAL (axis-aligned IoU, a few flops per pair): wave w of the block owns rows 16w..16w+15, and one ballot over the 64 column
+//          lanes per row IS the mask word.
+//   rotated: most pairs of a tile are far apart, so a cheap circumscribed-circle test first compacts the candidate (row, column)
+//          pairs of the tile into an LDS queue; the exact polygon-clipping IoU then runs only for the queued pairs, one pair
+//          per lane, and a lane whose pair exceeds the threshold sets its bit with an LDS atomicOr into the tile's 64 words.
 // ---------------------------------------------------------------------------------------------------
 template <int NORMAL>
 __global__ __launch_bounds__(kBlock) void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,

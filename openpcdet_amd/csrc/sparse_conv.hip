@@ -281,8 +281,6 @@ __global__ __launch_bounds__(kBlk) void sparse_conv_mfma_kernel(const E* __restr
 constexpr int kMaxKLds = 32;
 constexpr int kResidentBytes = 112 * 1024;
 
-// diagnostic build only (PVX_ABLATE bit 32): per-workgroup cycle sums of the tile phases, read back by pvx_debug_conv_stamps
-__device__ unsigned long long g_conv_stamps[1024 * 8];
 
 
 template <int CIN, int COUT, int NT> struct Plan {
@@ -302,7 +300,8 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
                                                                int K, int n_out, const int* __restrict__ n_out_dev,
                                                                const float* __restrict__ bias, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const E* __restrict__ residual,
-                                                               int relu, E* __restrict__ out, int dbg) {
+                                                               int relu, E* __restrict__ out) {
+    constexpr int dbg = 0;                                     // round-1 timing ablations, compiled out
     typedef Tiling<CIN, COUT> TL;
     typedef Plan<CIN, COUT, NT> PL;
     constexpr int T = TL::T, S = TL::S, TM = (NT / 64) * 16 * MT;
@@ -543,9 +542,7 @@ __global__ __launch_bounds__(NT) void sparse_conv_mfma2_kernel(const E* __restri
             st_sum[0] += st1 - st0; st_sum[1] += st2 - st1; st_sum[2] += st3 - st2; st_sum[3] += st4 - st3; st_sum[4] += 1;
         }
     }
-    if ((dbg & 32) && tid == 0 && blockIdx.x < 1024) {
-        for (int q = 0; q < 5; q++) g_conv_stamps[blockIdx.x * 8 + q] = st_sum[q];
-    }
+    (void)st_sum;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -639,32 +636,9 @@ int num_cus() {
     return (cus + 7) / 8 * 8;
 }
 
-// timing-only ablation (cdna_hip_programming.md section 7): PVX_ABLATE_GATHER=1 gives the feature buffer descriptor
-// zero records, so every gather is dropped by the range check while the instruction stream stays (results are wrong)
-bool ablate_gather() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PVX_ABLATE_GATHER"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-// PVX_ABLATE=<bits>: 1 no MFMA block, 2 no weight streaming, 4 no main-loop barriers, 8 no epilogue stores, 16 no
-// rulebook staging loads.  Timing experiments only (results are wrong); 0 / unset in production.
-int ablate_bits() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PVX_ABLATE"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
-// PVX_CONV_IMPL=2 forces the 16x16x32 kernels everywhere; default 3 = 32x32x16 kernels for the shapes they take
-int conv_impl() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PVX_CONV_IMPL"); v = e ? atoi(e) : 3; }
-    return v;
-}
-
 #include "sparse_conv_w32.h"
 #include "sparse_conv_slab.h"
 #include "sparse_conv_slab_tb.h"
-#include "sparse_conv_v3.h"
 
 long long prepared_elems(int cout, int K, int cin, int dtype) {
     if (w32_shape(cin, cout, K, dtype)) {
@@ -684,8 +658,8 @@ template <typename E, int CIN, int COUT>
 int launch_mfma(const void* feat, int n_in, const void* w, const int* nbr, int K, int n_out, const int* n_out_dev,
                 const float* bias, const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
     unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
-    if (ablate_gather() && feat_bytes < 0x80000000ull) feat_bytes = 0;
-    constexpr bool kPipelined = Plan<CIN, COUT, 512>::GROUP_BYTES <= 32768;   // one (offset, all couts) slab per 32-KiB chunk
+    // one (offset, all couts) slab per 32-KiB chunk; shapes the 32x32x16 kernels take (K <= 32) never get here with K <= 32
+    constexpr bool kPipelined = Plan<CIN, COUT, 512>::GROUP_BYTES <= 32768 && !w32_has<CIN, COUT>();
     if constexpr (kPipelined) if (K <= kMaxKLds && feat_bytes < 0x80000000ull) {
         if constexpr (Plan<CIN, COUT, 512>::CAN_RESIDE) {
           if (K <= 27) {
@@ -708,7 +682,7 @@ int launch_mfma(const void* feat, int n_in, const void* w, const int* nbr, int K
             if (grid > tiles) grid = (tiles + 7) / 8 * 8;
             hipLaunchKernelGGL((sparse_conv_mfma2_kernel<E, CIN, COUT, MT, D, true, NT>), dim3(grid), dim3(NT), 0, st,
                                (const E*)feat, n_in, (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale,
-                               shift, (const E*)residual, relu, (E*)out, ablate_bits());
+                               shift, (const E*)residual, relu, (E*)out);
             return PVX_OK;
           }
         }
@@ -723,7 +697,7 @@ int launch_mfma(const void* feat, int n_in, const void* w, const int* nbr, int K
             if (grid > tiles) grid = (tiles + 7) / 8 * 8;
             hipLaunchKernelGGL((sparse_conv_mfma2_kernel<E, CIN, COUT, MT, D, false, NT>), dim3(grid), dim3(NT), 0, st,
                                (const E*)feat, n_in, (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale,
-                               shift, (const E*)residual, relu, (E*)out, ablate_bits());
+                               shift, (const E*)residual, relu, (E*)out);
         }
         return PVX_OK;
     }
@@ -752,12 +726,6 @@ int launch_generic(const void* feat, int n_in, int cin, const void* w, const int
 }
 
 }  // namespace
-
-extern "C" int pvx_debug_conv_stamps(unsigned long long* host_out, int n_words) {
-    if (!host_out || n_words <= 0 || n_words > 1024 * 8) return PVX_ERR_INVALID;
-    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_conv_stamps), (size_t)n_words * sizeof(unsigned long long)));
-    return PVX_OK;
-}
 
 extern "C" int pvx_sparse_conv_uses_mfma(int cin, int cout, int dtype) { return mfma_shape(cin, cout, dtype) ? 1 : 0; }
 
@@ -825,19 +793,7 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
                                         relu, out, tilebook, tilebook_rcap, stream);
         if (rc_st != PVX_ERR_RANGE) return rc_st;             // PVX_ERR_RANGE: not taken (no input rows, > 2 GiB of features): the forms below
     }
-    if (w32_shape(cin, cout, kvol, dtype) && v3_shape(cin, cout, kvol, dtype)) {
-        int rcv = PVX_ERR_INVALID;
-#define X(ci, co, ck, rc, nwb, wgs)                                                                                           \
-    if (cin == ci && cout == co) {                                                                                            \
-        if (dtype == PVX_BF16)                                                                                                \
-            rcv = launch_v3<__bf16, ci, co, ck, rc, nwb, wgs>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
-        else                                                                                                                  \
-            rcv = launch_v3<_Float16, ci, co, ck, rc, nwb, wgs>(feat_in, n_in, prepared_weight, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st); \
-    }
-        PVX_V3_SHAPES(X)
-#undef X
-        if (rcv != PVX_OK) return rcv;
-    } else if (tilebook && w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) &&
+    if (tilebook && w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) &&
                tilebook_rcap > 0 && tilebook_rcap == tilebook_rcap_of(cin, cout, kvol, dtype)) {
         int rct = PVX_ERR_INVALID;
 #define X(ci, co, rc, sm)                                                                                                     \

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
                                                              int K, int n_out, const int* __restrict__ n_out_dev,
                                                              const float* __restrict__ bias, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const E* __restrict__ residual,
-                                                             int relu, E* __restrict__ out, int dbg) {
+                                                             int relu, E* __restrict__ out) {
+    constexpr int dbg = 0;                                     // round-1 timing ablations, compiled out
     typedef Tiling32<CIN, COUT> TL;
     typedef Plan32<CIN, COUT, NT> PL;
     static_assert(D % 2 == 0, "ring depth must be even");
@@ -287,8 +288,15 @@ __global__ __launch_bounds__(NT) void sparse_conv_w32_kernel(const E* __restrict
 #define PVX_W32_SHAPES(X) X(16, 16) X(16, 32) X(32, 16) X(32, 32) X(32, 64) X(64, 32) X(64, 64) X(64, 128) X(128, 64) X(128, 128)
 
 inline bool w32_shape(int cin, int cout, int K, int dtype) {
-    if (dtype == PVX_F32 || K > kMaxKLds || conv_impl() != 3) return false;
+    if (dtype == PVX_F32 || K > kMaxKLds) return false;
 #define X(ci, co) if (cin == ci && cout == co) return true;
+    PVX_W32_SHAPES(X)
+#undef X
+    return false;
+}
+
+template <int CIN, int COUT> constexpr bool w32_has() {
+#define X(ci, co) if (CIN == ci && COUT == co) return true;
     PVX_W32_SHAPES(X)
 #undef X
     return false;
@@ -301,7 +309,6 @@ int launch_w32(const void* feat, int n_in, const void* w, const int* nbr, int K,
                const float* bias, const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
     unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;   // buffer-load offsets are 32 bit
-    if (ablate_gather()) feat_bytes = 0;
     constexpr int NT = 512;
     if constexpr (Plan32<CIN, COUT, NT>::CAN_RESIDE) {
         if (K <= 27) {
@@ -319,7 +326,7 @@ int launch_w32(const void* feat, int n_in, const void* w, const int* nbr, int K,
             if (grid > tiles) grid = (tiles + 7) / 8 * 8;
             hipLaunchKernelGGL((sparse_conv_w32_kernel<E, CIN, COUT, MT, D, true, NT>), dim3(grid), dim3(NT), 0, st, (const E*)feat, n_in,
                                (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale, shift,
-                               (const E*)residual, relu, (E*)out, ablate_bits());
+                               (const E*)residual, relu, (E*)out);
             return PVX_OK;
         }
     }
@@ -335,7 +342,7 @@ int launch_w32(const void* feat, int n_in, const void* w, const int* nbr, int K,
         if (grid > tiles) grid = (tiles + 7) / 8 * 8;
         hipLaunchKernelGGL((sparse_conv_w32_kernel<E, CIN, COUT, MT, D, false, NT>), dim3(grid), dim3(NT), 0, st, (const E*)feat, n_in,
                            (unsigned)feat_bytes, (const uint4*)w, nbr, K, n_out, n_out_dev, bias, scale, shift,
-                           (const E*)residual, relu, (E*)out, ablate_bits());
+                           (const E*)residual, relu, (E*)out);
     }
     return PVX_OK;
 }

@@ -432,7 +432,15 @@ class HotPathEngine:
                         if pending is not None:
                             main.wait_event(pending)
                             pending = None
-                        fn(m)
+                        rec = getattr(self, "conv_events", None)
+                        if rec is not None and name.startswith("conv"):     # measurement only: the launch's duration INSIDE the overlapped schedule
+                            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            a.record(main)
+                            fn(m)
+                            b.record(main)
+                            rec.append((name, a, b))
+                        else:
+                            fn(m)
                         if (mark_after is not None or mark2_after) and name.startswith("conv"):
                             n_conv += 1
                             if n_conv == mark_after:
@@ -447,13 +455,17 @@ class HotPathEngine:
             return d.view(d.shape[0], d.shape[1] * d.shape[2], d.shape[3], d.shape[4])
         return None
 
-    def _geo_stream(self):
-        if getattr(self, "_geo", None) is None:
-            self._geo = torch.cuda.Stream(device=self.device)
+    def _geo_stream(self, preset=None):
+        if getattr(self, "_geo_events", None) is None:
             n = 1 + sum(1 for name, _ in self.ops if name in self._GEOMETRY)
             self._geo_events = [torch.cuda.Event() for _ in range(n)]
             self._done = torch.cuda.Event()
             self._done.record(torch.cuda.current_stream(self.device))
+            self._geo = None
+        if preset is not None:
+            self._geo = preset
+        elif self._geo is None:
+            self._geo = torch.cuda.Stream(device=self.device)
         return self._geo
 
     def geometry_stream(self):
@@ -461,11 +473,10 @@ class HotPathEngine:
             return self._geo_stream()
 
     def use_geometry_stream(self, stream):
-        """run the geometry launches on `stream` instead of a
-        stream of the plan's own; call before the first forward(overlap=True)"""
+        """run the geometry launches on `stream` instead of a stream of the plan's own (two alternating plans share one: a process has
+        four hardware queues, and a schedule should not need more streams than that); call before the first forward(overlap=True)"""
         with torch.cuda.device(self.device):
-            self._geo_stream()
-            self._geo = stream
+            self._geo_stream(preset=stream)
 
     # ---- results (these DO synchronise: for tests / reporting, not for the hot loop) ---------------------------------
     def level_rows(self):

@@ -355,9 +355,10 @@ def test_engine_sorted_input_equals_first_come(cuda_device):
     assert torch.equal(bev_s, bev_f)
 
 
-def test_voxelize_ahead_cu_budget_and_masked_streams(cuda_device):
-    """the serving-loop knobs change scheduling only: voxelize-ahead on a third stream, a conv CU budget and CU-masked
-    streams all give the bits of the plain forward"""
+def test_voxelize_ahead_and_shared_geometry_stream(cuda_device):
+    """the serving-loop knobs change scheduling only: voxelize-ahead on a third stream, a `mark` event that holds a later
+    voxelization back, and a caller-provided geometry stream (bench.py shares one between its two plans) all give the bits of
+    the plain forward"""
     from openpcdet_amd import _lib
     L = _lib.lib()
     cfg = SMALL
@@ -391,3 +392,17 @@ def test_voxelize_ahead_cu_budget_and_masked_streams(cuda_device):
     got = eng.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
     torch.cuda.synchronize()
     assert torch.equal(got, want[0])
+    # 2. a geometry stream of the caller's: two plans on ONE shared stream, alternating batches as bench.py does
+    eng2 = engine.HotPathEngine(net, 2, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], 20000,
+                                dtype=torch.bfloat16, device=cuda_device)
+    shared = torch.cuda.Stream(device=cuda_device)
+    eng.use_geometry_stream(shared)
+    eng2.use_geometry_stream(shared)
+    assert eng.geometry_stream() is shared and eng2.geometry_stream() is shared
+    for rnd in range(2):
+        for plan, fr, w in ((eng, frames_a, want[0]), (eng2, frames_b, want[1])):
+            dev_frames = to_dev(fr)
+            plan.voxelize_ahead(side, load=lambda p=plan, d=dev_frames: p.load_points(d))
+            got = plan.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(got, w), (rnd, plan is eng)
