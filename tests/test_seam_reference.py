@@ -98,3 +98,64 @@ def test_reference_files_run_on_the_stand_in():
     t = sys.modules["spconv.pytorch"].SparseConvTensor(torch.zeros(3, 4), torch.zeros(3, 4, dtype=torch.int32), [2, 2, 2], 1)
     t2 = su.replace_feature(t, torch.ones(3, 4))
     assert float(t2.features.sum()) == 12.0
+
+
+# ---- spconv-1.x checkpoint layout --------------------------------------------------------------------------------
+CKPT_GOLDEN = os.path.join(os.path.dirname(GOLDEN), "ckpt_spconv1x_layout.json")
+
+
+def _load_gen(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(GOLDEN), name + ".py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen
+
+
+def test_spconv1x_checkpoint_layout_matches_golden():
+    """anywhere: a 1.x-layout state dict -- conv weights (k1, k2, k3, c_in, c_out) -- pushed through the rule of
+    detector3d_template.py:356-371 (restated here: shape mismatch on a spconv key -> try transpose(-1, -2), else permute(4, 0, 1, 2, 3);
+    keep a key only when its shape then fits) onto THIS package's modules gives the key / shape list the reference's own
+    _load_state_dict produced in the build container (tests/golden/ckpt_spconv1x_layout.json), and every weight comes back as the
+    tensor it was made from."""
+    import torch
+    from openpcdet_amd.spconv.pytorch.conv import SparseConvolution
+    gen = _load_gen("make_ckpt_layout_golden")
+    want = json.load(open(CKPT_GOLDEN))
+    assert set(want) == set(gen.models())
+    for name, make in gen.models().items():
+        holder = gen.Holder(make())
+        keys = _find_keys(holder, SparseConvolution)
+        assert all(k.startswith("backbone_3d.") for k in keys)
+        disk, native = gen.spconv1x_state(holder, keys, 17)
+        state = holder.state_dict()
+        update = {}
+        for k, v in disk.items():
+            if k in keys and k in state and state[k].shape != v.shape:
+                t = v.transpose(-1, -2)
+                if t.shape == state[k].shape:
+                    v = t.contiguous()
+                else:
+                    assert v.dim() == 5
+                    p = v.permute(4, 0, 1, 2, 3)
+                    if p.shape == state[k].shape:
+                        v = p.contiguous()
+            if k in state and state[k].shape == v.shape:
+                update[k] = v
+        holder.load_state_dict(update)          # strict: every key must have survived
+        loaded = holder.state_dict()
+        got = {k: {"disk": list(disk[k].shape), "loaded": list(loaded[k].shape), "spconv": k in keys, "updated": k in update,
+                   "equals_native": bool(torch.equal(loaded[k], native[k]))} for k in disk}
+        assert got == want[name], name
+        assert all(v["updated"] and v["equals_native"] for v in got.values())
+        # the layouts really differ: no spconv weight could have been loaded without the permutation
+        assert all(v["disk"] != v["loaded"] for v in got.values() if v["spconv"])
+        assert sum(v["spconv"] for v in got.values()) == {"VoxelBackBone8x": 12, "VoxelResBackBone8x": 21}[name]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/pcdet"), reason="the reference tree only exists in the build container")
+def test_reference_load_state_dict_on_the_stand_in():
+    """build container only: the reference's own Detector3DTemplate._load_state_dict and find_all_spconv_keys run on a detector-shaped
+    module tree of this package's backbones and reproduce the golden file"""
+    gen = _load_gen("make_ckpt_layout_golden")
+    got = gen.run_reference(gen.load_detector_template())
+    assert got == json.load(open(CKPT_GOLDEN)), "golden file is stale: run tests/golden/make_ckpt_layout_golden.py"

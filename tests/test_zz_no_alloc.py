@@ -70,3 +70,21 @@ def test_nms_static_limits_and_no_allocation(cuda_device):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info(cuda_device)
     assert free1 == free0                                   # device memory in use did not move
+
+
+def test_nms_static_golden_keep_lists(cuda_device):
+    """the reference-derived keep lists of tests/golden/iou3d_golden.npz (the reference's own CPU IoU + its greedy rule, made by
+    tests/golden/make_iou3d_golden.py) through pvx_nms_static: bit-exact, every case, back to back on one stream"""
+    import os
+    L = _lib.lib()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "iou3d_golden.npz"))
+    names = [str(s) for s in g["case_names"]]
+    assert len(names) == 8
+    for name in names + names[::-1]:        # a second pass in the other order: larger-then-smaller and smaller-then-larger neighbours
+        boxes = torch.from_numpy(g[name + "_boxes"]).to(cuda_device)
+        want = g[name + "_keep"]
+        rc, keep, num = _nms_static(L, boxes, float(g[name + "_thresh"]), 0)
+        torch.cuda.synchronize()
+        assert rc == _lib.PVX_OK
+        assert int(num.item()) == len(want), name
+        assert np.array_equal(keep[:len(want)].cpu().numpy(), want), name
