@@ -265,6 +265,17 @@ size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw);
 int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
                          int* perm, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
 
+/* A caller that keeps its index buffers from frame to frame (a serving plan) need not pay a fill of the whole grid per frame (340 MB
+ * for level 0 of the nuScenes grid at batch 16): pvx_site_index_build_clean / pvx_conv_out_index_clean are the two builders WITHOUT
+ * their fill -- precondition: every bitmap word of `index` is zero -- and pvx_site_index_unset restores that state after use by zeroing
+ * the entries of the words that hold the given sites (coords: the rows the index was built from, or the coords_out of
+ * pvx_conv_out_rulebook for an output index; n = their capacity, *n_dev the live count).  If *n_dev > n (rows were dropped at the
+ * capacity, so some marked cells are not in coords) the whole index is cleared instead.  No reference counterpart (spconv
+ * allocates and fills a fresh hash table per call). */
+int pvx_site_index_build_clean(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
+                               int* perm, int* n_unique, void* workspace, size_t workspace_bytes, void* stream);
+int pvx_site_index_unset(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index, void* stream);
+
 /* torch.unique(coords, dim=0, return_inverse=True) for coordinate rows: coords_out [out_capacity, 4] = the distinct
  * rows in ascending (b, z, y, x) order, inverse [n] = row of coords_out each input row maps to (-1 for rows outside the
  * grid or beyond out_capacity), *n_unique = their number; `index` is left holding the site index of coords_out.
@@ -299,6 +310,11 @@ int pvx_conv_out_shape(const int* in_shape, const int* ksize, const int* stride,
 int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
                        const int* ksize, const int* stride, const int* padding, const int* dilation, void* out_index,
                        int* n_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same without the fill of out_index (see pvx_site_index_build_clean). */
+int pvx_conv_out_index_clean(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
+                             const int* ksize, const int* stride, const int* padding, const int* dilation, void* out_index,
+                             int* n_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Step 2: coords_out [n_out, 4] in ascending key order (the row-order contract) and nbr [K][n_out] against the
  * input tensor's site index (in_perm as in pvx_site_index_build, NULL when input rows are already in key order). */
@@ -349,6 +365,20 @@ int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* p
                            const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
                            const float* scale, const float* shift, const void* residual, int relu, void* out,
                            const void* tilebook, int tilebook_rcap, void* stream);
+/* When EVERY conv layer that reads a submanifold rulebook reads it through one book (an inference plan: the layers of a level
+ * share a shape), the int32 rulebook is needed only where that book says "far" (a neighbour row outside the tile's window: a few
+ * per cent of the entries), not at 108 B per site.
+ *   pvx_subm_book            = pvx_subm_rulebook_tb that stores only those entries of nbr_far (same [27][n] addressing; every other
+ *                              entry is left untouched and must not be read)
+ *   pvx_sparse_conv_fwd_book = pvx_sparse_conv_fwd_tb restricted to the kernels that read the rulebook through the book: a call that
+ *                              none of them takes returns PVX_ERR_RANGE (no fall-back to a form that would read all of nbr).
+ * Results are bit-identical to pvx_subm_rulebook_tb + pvx_sparse_conv_fwd_tb.  No reference counterpart. */
+int pvx_subm_book(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                  const int* perm, const int* dilation, int* nbr_far, int rcap, void* book, void* stream);
+int pvx_sparse_conv_fwd_book(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                             const int* nbr_far, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
+                             const float* scale, const float* shift, const void* residual, int relu, void* out,
+                             const void* tilebook, int tilebook_rcap, void* stream);
 
 /* Backward, weight gradient: grad_weight[co, k, ci] (f32, the module parameter's [cout, kvol, cin] layout) =
  * sum over live output rows o of grad_out[o, co] * feat_in[nbr[k][o], ci]; feat_in / grad_out are of `dtype`, fp32

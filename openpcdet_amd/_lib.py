@@ -96,6 +96,13 @@ SIGNATURES = {
     "pvx_site_index_workspace_bytes": (c_size_t, [c_int, c_void_p]),
     "pvx_site_index_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "pvx_site_index_build_clean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_size_t, c_void_p]),
+    "pvx_site_index_unset": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "pvx_conv_out_index_clean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "pvx_subm_book": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p]),
     "pvx_subm_rulebook": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
     "pvx_subm_rulebook_tb": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -113,6 +120,8 @@ SIGNATURES = {
                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "pvx_sparse_conv_fwd_tb": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                        c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "pvx_sparse_conv_fwd_book": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "pvx_tilebook_rcap": (c_int, [c_int, c_int, c_int, c_int]),
     "pvx_tilebook_bytes": (c_size_t, [c_int]),
     "pvx_tilebook_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

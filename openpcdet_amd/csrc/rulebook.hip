@@ -122,6 +122,31 @@ __global__ __launch_bounds__(kBlk) void idx_setbits_kernel(const int* __restrict
     if (flags) flags[(key >> 6) / pvx::kScanBlock] = 1;      // every writer stores the same value
 }
 
+// The undo of idx_setbits / conv_out_setbits for a caller that keeps its index buffer between frames (pvx_site_index_unset): the entries
+// of the words that hold the given sites are zeroed, 16 B per site instead of a fill of the whole grid (level 0 of the nuScenes grid at
+// batch 16: 25 MB of scattered stores against a 340 MB fill).  When rows were dropped at the capacity (*n_dev > n_cap) their cells are not
+// in `coords`: every workgroup then clears a slice of the whole index instead, so the buffer is all-zero afterwards either way.
+__global__ __launch_bounds__(kBlk) void idx_unset_kernel(const int* __restrict__ coords, int n_cap, const int* __restrict__ n_dev,
+                                                          Dims s, IndexEntry* __restrict__ idx, long long words) {
+    const int total = n_dev ? *n_dev : n_cap;
+    uint4* raw = reinterpret_cast<uint4*>(idx);
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    if (total > n_cap) {
+        for (long long w = (long long)blockIdx.x * kBlk + threadIdx.x; w < words; w += (long long)gridDim.x * kBlk) raw[w] = zero;
+        return;
+    }
+    const int i = blockIdx.x * kBlk + threadIdx.x;
+    long long word = -1;
+    if (i < total) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        if (c.x >= 0 && c.x < s.b && c.y >= 0 && c.y < s.d && c.z >= 0 && c.z < s.h && c.w >= 0 && c.w < s.w)
+            word = lin_key(c.x, c.y, c.z, c.w, s) >> 6;
+    }
+    // rows in key order: x-neighbours share a word, one store per run of equal words within the wave
+    const long long prev = __shfl_up(word, 1);
+    if (word >= 0 && ((threadIdx.x & 63) == 0 || prev != word)) raw[word] = zero;
+}
+
 // Both passes keep the block of kScanBlock (1024) words per block sum but run it on kIdxThreads (256) threads, four consecutive
 // words each: a 1024-thread workgroup has to wait for a CU with 16 free wave slots, which the persistent conv workgroups of the
 // overlapped schedule rarely leave (idx_count ran 15x longer beside them than alone, profiles/r02_kernel_stats_overlapped_b16.csv).
@@ -239,7 +264,10 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
                                                                  const int* __restrict__ n_dev, Dims s,
                                                                  const IndexEntry* __restrict__ idx,
                                                                  const int* __restrict__ perm, int dd, int dh, int dw,
-                                                                 int* __restrict__ nbr, int rcap, uint4* __restrict__ book) {
+                                                                 int* __restrict__ nbr, int rcap, uint4* __restrict__ book,
+                                                                 int far_only) {
+    // far_only (pvx_subm_book): the caller's conv layers all read this rulebook through THIS book, and they read an int32 entry only
+    // where the book says kTbFar -- so only those entries are stored (a few per cent), not 108 B per site
     static_assert(kBlk == kTbTile, "one workgroup = one tile");
     __shared__ int g_lo[3], g_hi[3];
     const int n_live = live_rows(n, n_dev);
@@ -254,8 +282,10 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
         uint4 craw = make_uint4(0u, 0u, 0u, 0u);
         if (dw == 1) {                                          // uniform over the launch
             probe_3x3x3(idx, perm, c.x, c.y, c.z, c.w, dd, dh, s, v);
+            if (!far_only) {
 #pragma unroll
-            for (int k = 0; k < kTbK; k++) nbr[(size_t)k * n + o] = v[k];
+                for (int k = 0; k < kTbK; k++) nbr[(size_t)k * n + o] = v[k];
+            }
         } else
 #pragma unroll
         for (int k = 0; k < kTbK; k++) {
@@ -264,13 +294,18 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
                 const int r = rank_of_cached(idx, lin_key(c.x, z, y, x, s), cword, craw);
                 if (r >= 0) v[k] = perm ? perm[r] : r;
             }
-            nbr[(size_t)k * n + o] = v[k];
+            if (!far_only) nbr[(size_t)k * n + o] = v[k];
         }
     }
     int vb[kTbK];
 #pragma unroll
     for (int k = 0; k < kTbK; k++) vb[k] = v[k] >= n ? -1 : v[k];    // as pvx_tilebook_build with n_in = n
-    tilebook_emit(vb, threadIdx.x, rcap, book + (size_t)blockIdx.x * kTbU4, g_lo, g_hi);
+    const unsigned far = tilebook_emit(vb, threadIdx.x, rcap, book + (size_t)blockIdx.x * kTbU4, g_lo, g_hi);
+    if (far_only && far) {
+#pragma unroll
+        for (int k = 0; k < kTbK; k++)
+            if ((far >> k) & 1u) nbr[(size_t)k * n + o] = v[k];
+    }
 }
 
 // Strided conv, phase 1: mark every output cell reached by some (input site, offset).
@@ -469,9 +504,9 @@ extern "C" size_t pvx_site_index_workspace_bytes(int batch, const int* shape_dhw
     return z.total();
 }
 
-extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
-                                    void* index, int* perm, int* n_unique, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+namespace {
+int site_index_build_impl(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index, int* perm,
+                          int* n_unique, void* workspace, size_t workspace_bytes, void* stream, bool prezeroed) {
     if (n < 0 || !shape_dhw || !index || !n_unique || (n > 0 && !coords)) return PVX_ERR_INVALID;
     Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
     long long words;
@@ -484,7 +519,7 @@ extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, 
     int* flags = cv.take<int>(nblocks);
     if (!cv.ok()) return PVX_ERR_WORKSPACE;
     IndexEntry* idx = (IndexEntry*)index;
-    PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
+    if (!prezeroed) PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
     PVX_CHECK_HIP(hipMemsetAsync(flags, 0, nblocks * sizeof(int), st));
     if (n > 0) {
         hipLaunchKernelGGL(idx_setbits_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx, flags);
@@ -496,6 +531,33 @@ extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, 
         hipLaunchKernelGGL(idx_perm_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, st, coords, n, n_dev, s, idx, perm);
         PVX_CHECK_LAUNCH();
     }
+    return PVX_OK;
+}
+}  // namespace
+
+extern "C" int pvx_site_index_build(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                    void* index, int* perm, int* n_unique, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    return site_index_build_impl(coords, n, n_dev, batch, shape_dhw, index, perm, n_unique, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int pvx_site_index_build_clean(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                          void* index, int* perm, int* n_unique, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    return site_index_build_impl(coords, n, n_dev, batch, shape_dhw, index, perm, n_unique, workspace, workspace_bytes, stream, true);
+}
+
+extern "C" int pvx_site_index_unset(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, void* index,
+                                    void* stream) {
+    if (n < 0 || !shape_dhw || !index || (n > 0 && !coords)) return PVX_ERR_INVALID;
+    Dims s = { batch, shape_dhw[0], shape_dhw[1], shape_dhw[2] };
+    long long words;
+    if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
+    if (words > kMaxWords) return PVX_ERR_RANGE;
+    if (n == 0) return PVX_OK;
+    hipLaunchKernelGGL(idx_unset_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
+                       (IndexEntry*)index, words);
+    PVX_CHECK_LAUNCH();
     return PVX_OK;
 }
 
@@ -515,9 +577,9 @@ extern "C" int pvx_subm_rulebook(const int* coords, int n, const int* n_dev, int
     return PVX_OK;
 }
 
-extern "C" int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
-                                    const void* index, const int* perm, const int* dilation, int* nbr, int rcap, void* book,
-                                    void* stream) {
+namespace {
+int subm_rulebook_tb_impl(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                          const int* perm, const int* dilation, int* nbr, int rcap, void* book, void* stream, int far_only) {
     if (n < 0 || !shape_dhw || !dilation || rcap <= 0 || rcap >= (int)kTbFar) return PVX_ERR_INVALID;
     if (n == 0) return PVX_OK;
     if (!coords || !index || !nbr || !book) return PVX_ERR_INVALID;
@@ -526,9 +588,21 @@ extern "C" int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, 
     if (!dims_ok(s, &words)) return PVX_ERR_INVALID;
     for (int j = 0; j < 3; j++) if (dilation[j] <= 0) return PVX_ERR_INVALID;
     hipLaunchKernelGGL(subm_rulebook_tb_kernel, dim3(PVX_CDIV(n, kBlk)), dim3(kBlk), 0, (hipStream_t)stream, coords, n, n_dev, s,
-                       (const IndexEntry*)index, perm, dilation[0], dilation[1], dilation[2], nbr, rcap, (uint4*)book);
+                       (const IndexEntry*)index, perm, dilation[0], dilation[1], dilation[2], nbr, rcap, (uint4*)book, far_only);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
+}
+}  // namespace
+
+extern "C" int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw,
+                                    const void* index, const int* perm, const int* dilation, int* nbr, int rcap, void* book,
+                                    void* stream) {
+    return subm_rulebook_tb_impl(coords, n, n_dev, batch, shape_dhw, index, perm, dilation, nbr, rcap, book, stream, 0);
+}
+
+extern "C" int pvx_subm_book(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
+                             const int* perm, const int* dilation, int* nbr_far, int rcap, void* book, void* stream) {
+    return subm_rulebook_tb_impl(coords, n, n_dev, batch, shape_dhw, index, perm, dilation, nbr_far, rcap, book, stream, 1);
 }
 
 extern "C" int pvx_conv_out_shape(const int* in_shape, const int* ksize, const int* stride, const int* padding,
@@ -541,9 +615,10 @@ extern "C" int pvx_conv_out_shape(const int* in_shape, const int* ksize, const i
     return PVX_OK;
 }
 
-extern "C" int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
-                                  const int* ksize, const int* stride, const int* padding, const int* dilation,
-                                  void* out_index, int* n_out, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int conv_out_index_impl(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape, const int* ksize,
+                        const int* stride, const int* padding, const int* dilation, void* out_index, int* n_out, void* workspace,
+                        size_t workspace_bytes, void* stream, bool prezeroed) {
     ConvGeom g;
     int rc = read_geom(in_shape, batch, ksize, stride, padding, dilation, &g);
     if (rc != PVX_OK) return rc;
@@ -556,12 +631,27 @@ extern "C" int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_i
     int* block_sums = cv.take<int>((size_t)PVX_CDIV(words, (long long)pvx::kScanBlock));
     if (!cv.ok()) return PVX_ERR_WORKSPACE;
     IndexEntry* idx = (IndexEntry*)out_index;
-    PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
+    if (!prezeroed) PVX_CHECK_HIP(hipMemsetAsync(idx, 0, (size_t)words * sizeof(IndexEntry), st));
     if (n_in > 0) {
         hipLaunchKernelGGL(conv_out_setbits_kernel, dim3(PVX_CDIV(n_in, kBlk)), dim3(kBlk), 0, st, coords_in, n_in, n_in_dev, g, idx);
         PVX_CHECK_LAUNCH();
     }
     return scan_index(idx, words, block_sums, nullptr, n_out, st);
+}
+}  // namespace
+
+extern "C" int pvx_conv_out_index(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
+                                  const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                  void* out_index, int* n_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_out_index_impl(coords_in, n_in, n_in_dev, batch, in_shape, ksize, stride, padding, dilation, out_index, n_out,
+                               workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int pvx_conv_out_index_clean(const int* coords_in, int n_in, const int* n_in_dev, int batch, const int* in_shape,
+                                        const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                        void* out_index, int* n_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_out_index_impl(coords_in, n_in, n_in_dev, batch, in_shape, ksize, stride, padding, dilation, out_index, n_out,
+                               workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,

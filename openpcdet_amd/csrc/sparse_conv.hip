@@ -781,7 +781,10 @@ extern "C" int pvx_sparse_conv_prepare_weight(const void* weight, int cout, int 
 static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
                          const int* nbr, int kvol, int n_out, const int* n_out_dev, int cout, int dtype, const float* scale,
                          const float* shift, const void* residual, int relu, void* out, const void* tilebook, int tilebook_rcap,
-                         void* stream) {
+                         void* stream, bool book_only = false) {
+    // book_only (pvx_sparse_conv_fwd_book): `nbr` holds the book's far entries only, so only the kernels that read the rulebook through
+    // the book may run; a call none of them takes fails instead of falling back to a form that reads all of nbr
+    if (book_only && (!tilebook || tilebook_rcap <= 0)) return PVX_ERR_INVALID;
     if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || dtype < 0 || dtype > 2) return PVX_ERR_INVALID;
     if ((scale == nullptr) != (shift == nullptr)) return PVX_ERR_INVALID;
     if (n_out == 0) return PVX_OK;
@@ -792,6 +795,7 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
         const int rc_st = pvx_st_launch(feat_in, n_in, cin, prepared_weight, bias, nbr, n_out, n_out_dev, cout, dtype, scale, shift, residual,
                                         relu, out, tilebook, tilebook_rcap, stream);
         if (rc_st != PVX_ERR_RANGE) return rc_st;             // PVX_ERR_RANGE: not taken (no input rows, > 2 GiB of features): the forms below
+        if (book_only) return PVX_ERR_RANGE;                  // (a book with the super-tile window fits no other form)
     }
     if (tilebook && w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) &&
                tilebook_rcap > 0 && tilebook_rcap == tilebook_rcap_of(cin, cout, kvol, dtype)) {
@@ -806,6 +810,8 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
         PVX_SLAB_SHAPES(X)
 #undef X
         if (rct != PVX_OK) return rct;
+    } else if (book_only) {
+        return PVX_ERR_RANGE;
     } else if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
         int rcs = PVX_ERR_INVALID;
 #define X(ci, co, rc, sm)                                                                                                     \
@@ -864,6 +870,14 @@ extern "C" int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, co
                                       const void* tilebook, int tilebook_rcap, void* stream) {
     return conv_fwd_impl(feat_in, n_in, cin, prepared_weight, bias, nbr, kvol, n_out, n_out_dev, cout, dtype, scale, shift, residual, relu,
                          out, tilebook, tilebook_rcap, stream);
+}
+
+extern "C" int pvx_sparse_conv_fwd_book(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,
+                                        const int* nbr_far, int kvol, int n_out, const int* n_out_dev, int cout, int dtype,
+                                        const float* scale, const float* shift, const void* residual, int relu, void* out,
+                                        const void* tilebook, int tilebook_rcap, void* stream) {
+    return conv_fwd_impl(feat_in, n_in, cin, prepared_weight, bias, nbr_far, kvol, n_out, n_out_dev, cout, dtype, scale, shift, residual,
+                         relu, out, tilebook, tilebook_rcap, stream, true);
 }
 
 extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {

@@ -7,8 +7,9 @@ constexpr int kTbU4 = 2 + kTbK * kTbTile * 2 / 16;             // 866 uint4 per 
 constexpr unsigned kTbNone = 0xFFFFu, kTbFar = 0xFFFEu;
 
 // v[k] = neighbour row of this thread's site at offset k (-1 = none; sites past the live count pass -1 everywhere).  Called by all
-// kTbTile threads of the workgroup that owns the tile; g_lo / g_hi are 3-entry LDS arrays.
-__device__ __forceinline__ void tilebook_emit(const int (&v)[kTbK], int tid, int rcap, uint4* __restrict__ blk, int* g_lo, int* g_hi) {
+// kTbTile threads of the workgroup that owns the tile; g_lo / g_hi are 3-entry LDS arrays.  Returns the thread's FAR mask: bit k set
+// <=> its entry k got the code kTbFar (the conv kernels read exactly those entries from the int32 rulebook).
+__device__ __forceinline__ unsigned tilebook_emit(const int (&v)[kTbK], int tid, int rcap, uint4* __restrict__ blk, int* g_lo, int* g_hi) {
     const int lane = tid & 63;
     if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
     __syncthreads();
@@ -42,13 +43,16 @@ __device__ __forceinline__ void tilebook_emit(const int (&v)[kTbK], int tid, int
         blk[1] = make_uint4((unsigned)wlo[2], (unsigned)cnt[2], flags, 0u);
     }
     unsigned short* ent = reinterpret_cast<unsigned short*>(blk + 2);
+    unsigned far = 0;
 #pragma unroll
     for (int k = 0; k < kTbK; k++) {
         unsigned code = kTbNone;
         if (v[k] >= 0) {
             const int local = v[k] - wlo[k / 9];
             code = (local >= 0 && local < cnt[k / 9]) ? (unsigned)local : kTbFar;
+            if (code == kTbFar) far |= 1u << k;
         }
         ent[k * kTbTile + tid] = (unsigned short)code;
     }
+    return far;
 }

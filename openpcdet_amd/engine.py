@@ -88,7 +88,8 @@ class _Level:
         nbytes = L.pvx_site_index_bytes(batch, self.c_shape)
         if nbytes == 0:
             raise ValueError("grid %s x batch %d is outside what the site index supports" % (shape3, batch))
-        self.index = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        # zero-filled ONCE: the plan's builders are the *_clean forms and every forward leaves the buffer zero again (pvx_site_index_unset)
+        self.index = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         self.perm = torch.empty(cap, dtype=torch.int32, device=device) if with_perm else None
         self.ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, self.c_shape), device)
         self.subm_nbr = {}    # (ksize tuple, dilation tuple) -> [K, cap] int32
@@ -196,12 +197,19 @@ class HotPathEngine:
 
         self.ops = []          # (name, callable(stream))
         self._books = {}       # (rulebook address, window rows) -> tile book buffer
+        self._fused_books = {} # rulebook address -> (index in self.ops, arguments, window rows) of the launch that writes rulebook + book
         self._subm_ops = {}    # rulebook address -> (index in self.ops, arguments) of the launch that builds it, while it has no book
         # which (cin, cout) layers read their rulebook through a tile book: building one costs about as much as one 16 -> 16
         # layer saves, so it pays where several rulebook-bound layers share it -- the five 16 -> 16 layers of level 0 (104 -> 68 us
         # each at B = 16); 32 -> 32 and 64 -> 64 gain 0-3 %, less than their book costs (profiles/r02_tilebook.txt).
         # PVX_ENGINE_TILEBOOK=0 / all: none / every shape that has the form (A/B switch).
         self.tilebook_mode = os.environ.get("PVX_ENGINE_TILEBOOK", "1")
+        # the level indices are filled with zeros once and un-set after use (25 MB of scattered stores instead of a 340 MB fill per forward at
+        # level 0 of the nuScenes grid, batch 16); PVX_ENGINE_CLEAN_INDEX=0: the builders that fill (A/B switch)
+        self.clean_index = os.environ.get("PVX_ENGINE_CLEAN_INDEX", "1") != "0"
+        # a submanifold rulebook all of whose layers read it through ONE tile book is stored as that book + its far entries only
+        # (pvx_subm_book / pvx_sparse_conv_fwd_book); PVX_ENGINE_FAR_ONLY=0: full int32 rulebooks (A/B switch)
+        self.far_only = os.environ.get("PVX_ENGINE_FAR_ONLY", "1") != "0"
         self.conv_records = [] # per conv launch: dict(name, cin, cout, kvol, nbr, level_out) for flop accounting
         keep = []              # keeps ctypes arrays / tensors alive
         self._keep = keep
@@ -249,6 +257,7 @@ class HotPathEngine:
                         at, ra = fuse
                         af = ra[:7] + (ra[8], ra[9], rcap, _lib.ptr(book))
                         self.ops[at] = ("subm_rulebook", lambda st, a=af: _lib.check(L.pvx_subm_rulebook_tb(*a, st), "pvx_subm_rulebook_tb"))
+                        self._fused_books[nbr.data_ptr()] = (at, af, rcap)
                     else:
                         ab = (_lib.ptr(nbr), kvol, level_out.cap, _lib.ptr(level_out.n_dev), level_in.cap, rcap, _lib.ptr(book))
                         self.ops.append(("tilebook", lambda st, a=ab: _lib.check(L.pvx_tilebook_build(*a, st), "pvx_tilebook_build")))
@@ -259,14 +268,22 @@ class HotPathEngine:
             name = "conv%d_%dx%d_k%d" % (len(self.conv_records), cin, cout, kvol)
             self.ops.append((name, lambda st, a=args: _lib.check(L.pvx_sparse_conv_fwd_tb(*a, st), "pvx_sparse_conv_fwd_tb")))
             self.conv_records.append(dict(name=name, cin=cin, cin_real=conv.in_channels, cout=cout, kvol=kvol, nbr=nbr,
-                                          level_in=level_in, level_out=level_out, subm=conv.subm, residual=residual_buf is not None))
+                                          level_in=level_in, level_out=level_out, subm=conv.subm, residual=residual_buf is not None,
+                                          op=len(self.ops) - 1, args=args, rcap=rcap, book=book, far_only=False))
             return out, cout
 
         # site index of the input level
         self._n_unique0 = torch.zeros(1, dtype=torch.int32, device=dev)
         a0 = (_lib.ptr(self.vox_coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index), _lib.ptr(lvl.perm),
               _lib.ptr(self._n_unique0), _lib.ptr(lvl.ws), lvl.ws.numel())
-        self.ops.append(("site_index", lambda st, a=a0: _lib.check(L.pvx_site_index_build(*a, st), "pvx_site_index_build")))
+        build0 = L.pvx_site_index_build_clean if self.clean_index else L.pvx_site_index_build
+        self.ops.append(("site_index", lambda st, a=a0: _lib.check(build0(*a, st), "pvx_site_index_build")))
+
+        def add_unset(level, coords, name="index_unset"):
+            if self.clean_index:
+                au = (_lib.ptr(coords), level.cap, _lib.ptr(level.n_dev), B, level.c_shape, _lib.ptr(level.index))
+                self.ops.append((name, lambda st, a=au: _lib.check(L.pvx_site_index_unset(*a, st), "pvx_site_index_unset")))
+
         if self.sort_input:
             a0s = (_lib.ptr(self.vox_coords), lvl.cap, _lib.ptr(lvl.n_dev), B, lvl.c_shape, _lib.ptr(lvl.index),
                    _lib.ptr(self.vox_feat), row_bytes0, _lib.ptr(lvl.coords), _lib.ptr(self.feat0), _lib.ptr(self.rank0))
@@ -297,10 +314,12 @@ class HotPathEngine:
                               _lib.ptr(nxt.index), _lib.ptr(nxt.n_dev), _lib.ptr(nxt.ws), nxt.ws.numel())
                         a2 = (_lib.ptr(nxt.index), nxt.cap, _lib.ptr(nxt.n_dev), B, cur.c_shape, k3, s3, p3, d3,
                               _lib.ptr(cur.index), _lib.ptr(cur.perm), _lib.ptr(nxt.coords), _lib.ptr(nbr))
-                        self.ops.append(("conv_out_index",
-                                         lambda st, a=a1: _lib.check(L.pvx_conv_out_index(*a, st), "pvx_conv_out_index")))
+                        out_index = L.pvx_conv_out_index_clean if self.clean_index else L.pvx_conv_out_index
+                        self.ops.append(("conv_out_index", lambda st, a=a1: _lib.check(out_index(*a, st), "pvx_conv_out_index")))
                         self.ops.append(("conv_out_rulebook",
                                          lambda st, a=a2: _lib.check(L.pvx_conv_out_rulebook(*a, st), "pvx_conv_out_rulebook")))
+                        # the input level's index has had its last reader (its submanifold rulebooks were built before this conv)
+                        add_unset(cur, cur.coords)     # (level 0: the rows in key order after pvx_sort_sites mark the same cells)
                         cur_feat, cin_cur = add_conv(spec, cur, nxt, cur_feat, cin_cur, nbr, None, avoid=())
                         self.levels.append(nxt)
                         cur = nxt
@@ -331,6 +350,18 @@ class HotPathEngine:
                                                                       "pvx_sparse_to_dense_sorted")))
             else:
                 self.ops.append(("dense", lambda st, a=ad: _lib.check(L.pvx_sparse_to_dense(*a, st), "pvx_sparse_to_dense")))
+        # the last level's index is read by the line-form dense pass on the main stream: its un-set follows there
+        add_unset(cur, cur.coords, name="index_unset_main")
+        if self.far_only:
+            # rulebooks written together with their book (pvx_subm_rulebook_tb) whose every reader uses that very book
+            for ptr, (at, af, rcap) in self._fused_books.items():
+                readers = [r for r in self.conv_records if r["nbr"].data_ptr() == ptr]
+                if readers and all(r["rcap"] == rcap and r["book"] is self._books[(ptr, rcap)] for r in readers):
+                    self.ops[at] = ("subm_rulebook", lambda st, a=af: _lib.check(L.pvx_subm_book(*a, st), "pvx_subm_book"))
+                    for r in readers:
+                        r["far_only"] = True
+                        self.ops[r["op"]] = (r["name"], lambda st, a=r["args"]: _lib.check(L.pvx_sparse_conv_fwd_book(*a, st),
+                                                                                           "pvx_sparse_conv_fwd_book"))
         torch.cuda.synchronize(dev)
 
     # ------------------------------------------------------------------------------------------------------------
@@ -363,7 +394,7 @@ class HotPathEngine:
             for name, fn in self.ops:
                 hook(name, lambda: fn(st))
 
-    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook")
+    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook", "index_unset")
 
     def voxelize_ahead(self, stream, load=None, after=None):
         """Voxelize the NEXT batch of this plan on `stream` while another plan's rulebooks are being built: waits for this
@@ -502,7 +533,12 @@ class HotPathEngine:
         for r in self.conv_records:
             lvl = r["level_out"]
             n = min(int(lvl.n_dev.item()), lvl.cap)
-            pairs = int((r["nbr"][:, :n] >= 0).sum().item())
+            if r["far_only"]:    # the int32 rulebook holds the far entries only: count the book's codes (0xFFFF = no neighbour)
+                codes = r["book"].view(torch.int16).view(-1, 8 * self.L.pvx_tilebook_bytes(256) // 16)[:, 16:].reshape(-1, 27, 256)
+                live = (torch.arange(codes.shape[0] * 256, device=codes.device) < n).view(-1, 1, 256)
+                pairs = int(((codes != -1) & live).sum().item())
+            else:
+                pairs = int((r["nbr"][:, :n] >= 0).sum().item())
             f = 2 * pairs * r["cin_real"] * r["cout"]
             per.append((r["name"], n, pairs, f))
             total += f

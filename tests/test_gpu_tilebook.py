@@ -210,3 +210,118 @@ def test_fused_subm_rulebook_and_book(cuda_device, sort):
         assert np.array_equal(a[:, :7], b[:, :7]) and np.array_equal(a[:, 8:], b[:, 8:])
     assert L.pvx_subm_rulebook_tb(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), d3,
                                   _lib.ptr(nbr_b), 0, _lib.ptr(book_b), None) == -1
+
+
+def _run_conv_entry(entry, dev, feat, w, nbr_t, n_live_t, cin, cout, code, book, rcap):
+    L = _lib.lib()
+    cap = nbr_t.shape[1]
+    pw = torch.empty(L.pvx_sparse_conv_weight_bytes(cout, 27, cin, code), dtype=torch.uint8, device=dev)
+    _lib.check(L.pvx_sparse_conv_prepare_weight(_lib.ptr(w), cout, 27, cin, code, _lib.ptr(pw), _lib.stream()), "prepare")
+    out = torch.full((cap, cout), 7.0, dtype=feat.dtype, device=dev)
+    scale = torch.linspace(0.5, 1.5, cout, device=dev)
+    shift = torch.linspace(-0.2, 0.2, cout, device=dev)
+    bias = torch.linspace(-0.1, 0.1, cout, device=dev)
+    rc = getattr(L, entry)(_lib.ptr(feat), feat.shape[0], cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr_t), 27, cap, _lib.ptr(n_live_t),
+                           cout, code, _lib.ptr(scale), _lib.ptr(shift), None, 1, _lib.ptr(out), _lib.ptr(book), rcap, _lib.stream())
+    return rc, out
+
+
+@pytest.mark.parametrize("sort", [True, False])
+def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
+    """(1) pvx_site_index_build_clean on a zeroed buffer = pvx_site_index_build; pvx_site_index_unset leaves the buffer all-zero again, also
+    when rows were dropped at the capacity (*n_dev > n: the whole index is cleared).  (2) pvx_subm_book stores the same book and exactly
+    the far entries of the rulebook, and pvx_sparse_conv_fwd_book over them gives the bits of pvx_sparse_conv_fwd_tb over the full rulebook;
+    a shape without a book-form kernel is refused, not served by a kernel that would read the missing entries."""
+    L = _lib.lib()
+    dev = cuda_device
+    shape, batch = [10, 50, 300], 2
+    coords = sites(23, batch, shape, 40000, sort)
+    n = len(coords)
+    cap = n + 500
+    c4 = np.zeros((cap, 4), np.int32)
+    c4[:n] = coords
+    coords_t = torch.from_numpy(c4).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    s3 = _lib.int3(shape)
+    nbytes = L.pvx_site_index_bytes(batch, s3)
+    ws = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, s3), dev)
+    idx_a = torch.full((nbytes,), 0x5a, dtype=torch.uint8, device=dev)
+    idx_b = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    perm_a, perm_b = (torch.full((cap,), -3, dtype=torch.int32, device=dev) for _ in range(2))
+    nu_a, nu_b = (torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2))
+    _lib.check(L.pvx_site_index_build(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_a), _lib.ptr(perm_a), _lib.ptr(nu_a),
+                                      _lib.ptr(ws), ws.numel(), _lib.stream()), "index")
+    for rnd in range(2):                                        # the second round runs on the buffer the first round's un-set left
+        _lib.check(L.pvx_site_index_build_clean(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_b), _lib.ptr(perm_b),
+                                                _lib.ptr(nu_b), _lib.ptr(ws), ws.numel(), _lib.stream()), "index clean")
+        a = idx_a.view(torch.int32).view(-1, 4)
+        b = idx_b.view(torch.int32).view(-1, 4)
+        used = (a[:, 0] != 0) | (a[:, 1] != 0)
+        assert torch.equal(a[:, :2], b[:, :2]) and torch.equal(a[used, 2], b[used, 2])      # bits everywhere, prefix where a bit is set
+        assert torch.equal(perm_a, perm_b) and int(nu_a.item()) == int(nu_b.item()) == n
+        if rnd == 0:
+            _lib.check(L.pvx_site_index_unset(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_b), _lib.stream()), "unset")
+            assert int(idx_b.count_nonzero().item()) == 0
+    # rows dropped at the capacity: the caller's coords list is short of the marked cells
+    short = n - 1000
+    over = torch.tensor([n], dtype=torch.int32, device=dev)
+    _lib.check(L.pvx_site_index_unset(_lib.ptr(coords_t), short, _lib.ptr(over), batch, s3, _lib.ptr(idx_b), _lib.stream()), "unset all")
+    assert int(idx_b.count_nonzero().item()) == 0
+    # strided output index, clean form, and its un-set through coords_out
+    k3, st3, p3, d3 = _lib.int3([3, 3, 3]), _lib.int3([2, 2, 2]), _lib.int3([1, 1, 1]), _lib.int3([1, 1, 1])
+    o3 = (ctypes.c_int * 3)()
+    _lib.check(L.pvx_conv_out_shape(s3, k3, st3, p3, d3, o3), "shape")
+    obytes = L.pvx_site_index_bytes(batch, o3)
+    ows = _lib.workspace(L.pvx_site_index_workspace_bytes(batch, o3), dev)
+    oidx_a = torch.full((obytes,), 0x33, dtype=torch.uint8, device=dev)
+    oidx_b = torch.zeros(obytes, dtype=torch.uint8, device=dev)
+    no_a, no_b = (torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2))
+    for fn, oi, no in ((L.pvx_conv_out_index, oidx_a, no_a), (L.pvx_conv_out_index_clean, oidx_b, no_b)):
+        _lib.check(fn(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, k3, st3, p3, d3, _lib.ptr(oi), _lib.ptr(no), _lib.ptr(ows),
+                      ows.numel(), _lib.stream()), "out index")
+    assert torch.equal(oidx_a.view(torch.int32).view(-1, 4)[:, :3], oidx_b.view(torch.int32).view(-1, 4)[:, :3])
+    n_out = int(no_b.item())
+    assert n_out == int(no_a.item()) > 0
+    ocap = n_out + 10
+    ocoords = torch.zeros((ocap, 4), dtype=torch.int32, device=dev)
+    onbr = torch.zeros((27, ocap), dtype=torch.int32, device=dev)
+    _lib.check(L.pvx_conv_out_rulebook(_lib.ptr(oidx_b), ocap, _lib.ptr(no_b), batch, s3, k3, st3, p3, d3, _lib.ptr(idx_a), _lib.ptr(perm_a),
+                                       _lib.ptr(ocoords), _lib.ptr(onbr), _lib.stream()), "out rulebook")
+    _lib.check(L.pvx_site_index_unset(_lib.ptr(ocoords), ocap, _lib.ptr(no_b), batch, o3, _lib.ptr(oidx_b), _lib.stream()), "unset out")
+    assert int(oidx_b.count_nonzero().item()) == 0
+
+    # ---- far-only rulebook ----------------------------------------------------------------------------------------
+    cin, cout, code = 64, 64, _lib.DTYPE_CODE[torch.bfloat16]
+    rcap = L.pvx_tilebook_rcap(cin, cout, 27, code)
+    assert rcap > 0
+    nbr_full = torch.full((27, cap), -7, dtype=torch.int32, device=dev)
+    nbr_far = torch.full((27, cap), -7, dtype=torch.int32, device=dev)
+    book_a = torch.zeros(L.pvx_tilebook_bytes(cap), dtype=torch.uint8, device=dev)
+    book_b = torch.zeros(L.pvx_tilebook_bytes(cap), dtype=torch.uint8, device=dev)
+    _lib.check(L.pvx_subm_rulebook_tb(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_a), _lib.ptr(perm_a), d3,
+                                      _lib.ptr(nbr_full), rcap, _lib.ptr(book_a), _lib.stream()), "fused")
+    _lib.check(L.pvx_subm_book(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_a), _lib.ptr(perm_a), d3,
+                               _lib.ptr(nbr_far), rcap, _lib.ptr(book_b), _lib.stream()), "book")
+    tiles = (n + 255) // 256
+    a = book_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+    b = book_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+    assert np.array_equal(a[:, :7], b[:, :7]) and np.array_equal(a[:, 8:], b[:, 8:])
+    codes = np.ascontiguousarray(a[:, 8:]).view(np.uint16).reshape(tiles, 27, 256).transpose(1, 0, 2).reshape(27, tiles * 256)[:, :n]
+    far = codes == 0xFFFE
+    got_far, full = nbr_far[:, :n].cpu().numpy(), nbr_full[:, :n].cpu().numpy()
+    assert np.array_equal(got_far[far], full[far]) and np.all(got_far[~far] == -7)     # exactly the far entries, nothing else
+    assert far.any() == (not sort)                              # key order at this density: every neighbour inside the window
+    g = torch.Generator().manual_seed(5)
+    feat = torch.randn((cap, cin), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((cout, 27, cin), generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    rc_a, out_a = _run_conv_entry("pvx_sparse_conv_fwd_tb", dev, feat, w, nbr_full, n_dev, cin, cout, code, book_a, rcap)
+    rc_b, out_b = _run_conv_entry("pvx_sparse_conv_fwd_book", dev, feat, w, nbr_far, n_dev, cin, cout, code, book_b, rcap)
+    assert rc_a == 0 and rc_b == 0
+    assert torch.equal(out_a, out_b) and float(out_a[:n].float().abs().sum()) > 0
+    # no book-form kernel for this request: refused (PVX_ERR_RANGE / PVX_ERR_INVALID), not served from the incomplete rulebook
+    w128 = torch.zeros((128, 27, 128), dtype=torch.bfloat16, device=dev)
+    f128 = torch.zeros((cap, 128), dtype=torch.bfloat16, device=dev)
+    rc, _ = _run_conv_entry("pvx_sparse_conv_fwd_book", dev, f128, w128, nbr_far, n_dev, 128, 128, code, book_b, rcap)
+    assert rc == -4
+    rc, _ = _run_conv_entry("pvx_sparse_conv_fwd_book", dev, feat, w, nbr_far, n_dev, cin, cout, code, None, 0)
+    assert rc == -1
