@@ -373,6 +373,12 @@ int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* p
  *   pvx_sparse_conv_fwd_book = pvx_sparse_conv_fwd_tb restricted to the kernels that read the rulebook through the book: a call that
  *                              none of them takes returns PVX_ERR_RANGE (no fall-back to a form that would read all of nbr).
  * Results are bit-identical to pvx_subm_rulebook_tb + pvx_sparse_conv_fwd_tb.  No reference counterpart. */
+/* pvx_conv_out_rulebook for a 3 x 3 x 3 kernel that also writes the tile book of its rulebook (window rcap; entries >= n_in count as
+ * absent, as in pvx_tilebook_build) in the same pass; far_only != 0: nbr receives only the entries the book marks "far" (for
+ * pvx_sparse_conv_fwd_book), else the whole rulebook as pvx_conv_out_rulebook writes it.  Same values either way. */
+int pvx_conv_out_book(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape, const int* ksize,
+                      const int* stride, const int* padding, const int* dilation, const void* in_index, const int* in_perm,
+                      int* coords_out, int* nbr, int n_in, int rcap, void* book, int far_only, void* stream);
 int pvx_subm_book(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
                   const int* perm, const int* dilation, int* nbr_far, int rcap, void* book, void* stream);
 int pvx_sparse_conv_fwd_book(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,

@@ -112,6 +112,8 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "pvx_conv_out_rulebook": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pvx_conv_out_book": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "pvx_inverse_rulebook": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pvx_sparse_conv_uses_mfma": (c_int, [c_int, c_int, c_int]),
     "pvx_sparse_conv_weight_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

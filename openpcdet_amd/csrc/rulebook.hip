@@ -399,23 +399,48 @@ __global__ __launch_bounds__(kBlk) void conv_out_coords_kernel(const IndexEntry*
     }
 }
 
-// phase 2b: thread = output site, loop over offsets, look the input cell up in the INPUT index
+// phase 2b: thread = output site, loop over offsets, look the input cell up in the INPUT index.
+// book != NULL (pvx_conv_out_book, 3 x 3 x 3 only): the workgroup's 256 output sites are one tile and their 27 entries are in registers,
+// so the rulebook's tile book is written in the same pass, as subm_rulebook_tb_kernel does; with far_only the int32 rulebook gets only
+// the entries the book marks "far".
 __global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __restrict__ coords_out, int n_out,
                                                                   const int* __restrict__ n_out_dev, ConvGeom g,
                                                                   const IndexEntry* __restrict__ in_idx,
                                                                   const int* __restrict__ in_perm,
-                                                                  int* __restrict__ nbr) {
+                                                                  int* __restrict__ nbr, int n_in, int rcap,
+                                                                  uint4* __restrict__ book, int far_only) {
+    __shared__ int g_lo[3], g_hi[3];
+    const int n_live = live_rows(n_out, n_out_dev);
+    if ((int)blockIdx.x * kBlk >= n_live) return;              // the whole workgroup
     const int o = blockIdx.x * kBlk + threadIdx.x;
-    if (o >= live_rows(n_out, n_out_dev)) return;
-    const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
     if (g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 && g.dil[2] == 1) {      // uniform over the launch
         int v[27];
-        probe_3x3x3(in_idx, in_perm, c.x, c.y * g.s[0] - g.p[0] + g.dil[0], c.z * g.s[1] - g.p[1] + g.dil[1],
-                    c.w * g.s[2] - g.p[2] + 1, g.dil[0], g.dil[1], g.in, v);
 #pragma unroll
-        for (int k = 0; k < 27; k++) nbr[(size_t)k * n_out + o] = v[k];
+        for (int k = 0; k < 27; k++) v[k] = -1;
+        if (o < n_live) {
+            const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
+            probe_3x3x3(in_idx, in_perm, c.x, c.y * g.s[0] - g.p[0] + g.dil[0], c.z * g.s[1] - g.p[1] + g.dil[1],
+                        c.w * g.s[2] - g.p[2] + 1, g.dil[0], g.dil[1], g.in, v);
+            if (!(book && far_only)) {
+#pragma unroll
+                for (int k = 0; k < 27; k++) nbr[(size_t)k * n_out + o] = v[k];
+            }
+        }
+        if (book) {
+            int vb[kTbK];
+#pragma unroll
+            for (int k = 0; k < kTbK; k++) vb[k] = v[k] >= n_in ? -1 : v[k];    // as pvx_tilebook_build
+            const unsigned far = tilebook_emit(vb, threadIdx.x, rcap, book + (size_t)blockIdx.x * kTbU4, g_lo, g_hi);
+            if (far_only && far) {
+#pragma unroll
+                for (int k = 0; k < kTbK; k++)
+                    if ((far >> k) & 1u) nbr[(size_t)k * n_out + o] = v[k];
+            }
+        }
         return;
     }
+    if (o >= n_live) return;
+    const int4 c = reinterpret_cast<const int4*>(coords_out)[o];
     int k = 0;
     long long cword = -1;
     uint4 craw = make_uint4(0u, 0u, 0u, 0u);
@@ -654,9 +679,10 @@ extern "C" int pvx_conv_out_index_clean(const int* coords_in, int n_in, const in
                                workspace, workspace_bytes, stream, true);
 }
 
-extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
-                                     const int* ksize, const int* stride, const int* padding, const int* dilation,
-                                     const void* in_index, const int* in_perm, int* coords_out, int* nbr, void* stream) {
+namespace {
+int conv_out_rulebook_impl(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape, const int* ksize,
+                           const int* stride, const int* padding, const int* dilation, const void* in_index, const int* in_perm,
+                           int* coords_out, int* nbr, void* stream, int n_in, int rcap, void* book, int far_only) {
     ConvGeom g;
     int rc = read_geom(in_shape, batch, ksize, stride, padding, dilation, &g);
     if (rc != PVX_OK) return rc;
@@ -669,10 +695,28 @@ extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int
     hipLaunchKernelGGL(conv_out_coords_kernel, dim3((unsigned)PVX_CDIV(words, (long long)kBlk)), dim3(kBlk), 0, st,
                        (const IndexEntry*)out_index, words, g.out, n_out, coords_out);
     PVX_CHECK_LAUNCH();
+    if (book && !(g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 && g.dil[2] == 1)) return PVX_ERR_INVALID;
     hipLaunchKernelGGL(conv_out_rulebook_kernel, dim3(PVX_CDIV(n_out, kBlk)), dim3(kBlk), 0, st, coords_out, n_out, n_out_dev, g,
-                       (const IndexEntry*)in_index, in_perm, nbr);
+                       (const IndexEntry*)in_index, in_perm, nbr, n_in, rcap, (uint4*)book, far_only);
     PVX_CHECK_LAUNCH();
     return PVX_OK;
+}
+}  // namespace
+
+extern "C" int pvx_conv_out_rulebook(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
+                                     const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                     const void* in_index, const int* in_perm, int* coords_out, int* nbr, void* stream) {
+    return conv_out_rulebook_impl(out_index, n_out, n_out_dev, batch, in_shape, ksize, stride, padding, dilation, in_index, in_perm,
+                                  coords_out, nbr, stream, 0, 0, nullptr, 0);
+}
+
+extern "C" int pvx_conv_out_book(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape,
+                                 const int* ksize, const int* stride, const int* padding, const int* dilation,
+                                 const void* in_index, const int* in_perm, int* coords_out, int* nbr, int n_in, int rcap,
+                                 void* book, int far_only, void* stream) {
+    if (n_in < 0 || rcap <= 0 || rcap >= (int)kTbFar || (n_out > 0 && !book)) return PVX_ERR_INVALID;
+    return conv_out_rulebook_impl(out_index, n_out, n_out_dev, batch, in_shape, ksize, stride, padding, dilation, in_index, in_perm,
+                                  coords_out, nbr, stream, n_in, rcap, book, far_only ? 1 : 0);
 }
 
 extern "C" int pvx_inverse_rulebook(const int* nbr_fwd, int kvol, int n_out_fwd, int n_in_fwd, int* nbr_inv, void* stream) {

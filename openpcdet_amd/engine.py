@@ -129,7 +129,7 @@ class HotPathEngine:
 
     # layers that share a rulebook with enough launches to pay for its book (55 us): the five 16 -> 16 layers (bound by rulebook
     # bytes) and the four 32 -> 32 layers (the rolling kernel form needs the book's window spans a tile ahead)
-    TILEBOOK_SHAPES = {(16, 16), (32, 32), (64, 64)}
+    TILEBOOK_SHAPES = {(16, 16), (16, 32), (32, 32), (64, 64)}    # (32, 64): its book form measured slower (282 vs 254 us)
 
     def _wants_tilebook(self, cin, cout):
         if self.tilebook_mode == "0":
@@ -316,11 +316,30 @@ class HotPathEngine:
                               _lib.ptr(cur.index), _lib.ptr(cur.perm), _lib.ptr(nxt.coords), _lib.ptr(nbr))
                         out_index = L.pvx_conv_out_index_clean if self.clean_index else L.pvx_conv_out_index
                         self.ops.append(("conv_out_index", lambda st, a=a1: _lib.check(out_index(*a, st), "pvx_conv_out_index")))
-                        self.ops.append(("conv_out_rulebook",
-                                         lambda st, a=a2: _lib.check(L.pvx_conv_out_rulebook(*a, st), "pvx_conv_out_rulebook")))
+                        # a strided conv whose kernel has the tile-book form: the rulebook launch writes the book too, and (one reader)
+                        # only the book's far entries of the int32 rulebook
+                        rcap_s = 0
+                        if tuple(conv.kernel_size) == (3, 3, 3) and conv.dilation[2] == 1 and self._wants_tilebook(cin_cur, conv.out_channels) \
+                                and os.environ.get("PVX_ENGINE_FUSED_BOOK", "1") != "0":
+                            rcap_s = L.pvx_tilebook_rcap(cin_cur, conv.out_channels, kvol, self.code)
+                        if rcap_s > 0:
+                            book_s = torch.empty(L.pvx_tilebook_bytes(nxt.cap), dtype=torch.uint8, device=dev)
+                            self._books[(nbr.data_ptr(), rcap_s)] = book_s
+                            a2b = a2 + (cur.cap, rcap_s, _lib.ptr(book_s), 1 if self.far_only else 0)
+                            self.ops.append(("conv_out_rulebook",
+                                             lambda st, a=a2b: _lib.check(L.pvx_conv_out_book(*a, st), "pvx_conv_out_book")))
+                        else:
+                            self.ops.append(("conv_out_rulebook",
+                                             lambda st, a=a2: _lib.check(L.pvx_conv_out_rulebook(*a, st), "pvx_conv_out_rulebook")))
                         # the input level's index has had its last reader (its submanifold rulebooks were built before this conv)
                         add_unset(cur, cur.coords)     # (level 0: the rows in key order after pvx_sort_sites mark the same cells)
                         cur_feat, cin_cur = add_conv(spec, cur, nxt, cur_feat, cin_cur, nbr, None, avoid=())
+                        if rcap_s > 0 and self.far_only:
+                            r = self.conv_records[-1]
+                            assert r["rcap"] == rcap_s and r["book"] is book_s
+                            r["far_only"] = True
+                            self.ops[r["op"]] = (r["name"], lambda st, a=r["args"]: _lib.check(L.pvx_sparse_conv_fwd_book(*a, st),
+                                                                                               "pvx_sparse_conv_fwd_book"))
                         self.levels.append(nxt)
                         cur = nxt
                 else:   # residual block

@@ -287,6 +287,31 @@ def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
     onbr = torch.zeros((27, ocap), dtype=torch.int32, device=dev)
     _lib.check(L.pvx_conv_out_rulebook(_lib.ptr(oidx_b), ocap, _lib.ptr(no_b), batch, s3, k3, st3, p3, d3, _lib.ptr(idx_a), _lib.ptr(perm_a),
                                        _lib.ptr(ocoords), _lib.ptr(onbr), _lib.stream()), "out rulebook")
+    # the strided rulebook with its tile book in one pass (pvx_conv_out_book), full and far-only
+    rc16 = L.pvx_tilebook_rcap(16, 32, 27, _lib.DTYPE_CODE[torch.bfloat16])
+    assert rc16 > 0
+    for rcap_o in (rc16, 64):                                   # 64 rows: most neighbours outside the window
+        obook_a = torch.zeros(L.pvx_tilebook_bytes(ocap), dtype=torch.uint8, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(onbr), 27, ocap, _lib.ptr(no_b), cap, rcap_o, _lib.ptr(obook_a), _lib.stream()), "build")
+        otiles = (n_out + 255) // 256
+        want_book = obook_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:otiles]
+        ocodes = np.ascontiguousarray(want_book[:, 8:]).view(np.uint16).reshape(otiles, 27, 256).transpose(1, 0, 2).reshape(27, otiles * 256)[:, :n_out]
+        for far_only in (0, 1):
+            obook_b = torch.zeros(L.pvx_tilebook_bytes(ocap), dtype=torch.uint8, device=dev)
+            onbr_b = torch.full((27, ocap), -7, dtype=torch.int32, device=dev)
+            ocoords_b = torch.zeros((ocap, 4), dtype=torch.int32, device=dev)
+            _lib.check(L.pvx_conv_out_book(_lib.ptr(oidx_b), ocap, _lib.ptr(no_b), batch, s3, k3, st3, p3, d3, _lib.ptr(idx_a), _lib.ptr(perm_a),
+                                           _lib.ptr(ocoords_b), _lib.ptr(onbr_b), cap, rcap_o, _lib.ptr(obook_b), far_only, _lib.stream()), "out book")
+            got_book = obook_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:otiles]
+            assert np.array_equal(want_book[:, :7], got_book[:, :7]) and np.array_equal(want_book[:, 8:], got_book[:, 8:])
+            assert torch.equal(ocoords_b, ocoords)
+            if far_only:
+                farm = ocodes == 0xFFFE
+                g_, f_ = onbr_b[:, :n_out].cpu().numpy(), onbr[:, :n_out].cpu().numpy()
+                assert np.array_equal(g_[farm], f_[farm]) and np.all(g_[~farm] == -7)
+                assert farm.any() or rcap_o == rc16
+            else:
+                assert torch.equal(onbr_b[:, :n_out], onbr[:, :n_out])
     _lib.check(L.pvx_site_index_unset(_lib.ptr(ocoords), ocap, _lib.ptr(no_b), batch, o3, _lib.ptr(oidx_b), _lib.stream()), "unset out")
     assert int(oidx_b.count_nonzero().item()) == 0
 
