@@ -91,7 +91,8 @@ extern "C" int pvx_debug_st_stamps(unsigned long long* host_out, int n_words) {
 #endif
 
 int pvx_st_rcap(int cin, int cout, int kvol, int dtype) {
-    if (kvol != 27 || (dtype != PVX_BF16 && dtype != PVX_F16) || st_mode() == 0) return 0;
+    if (kvol != 27 || (dtype != PVX_BF16 && dtype != PVX_F16)) return 0;
+    if (st_mode() == 0) return 0;
 #define X(ci, co, rc, ns) if (cin == ci && cout == co) return rc;
     PVX_ST_SHAPES(X)
 #undef X

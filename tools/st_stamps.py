@@ -55,6 +55,9 @@ def main():
                         w = a[:, 4:, q]
                         print("   %-26s %9.0f cyc per wave   (min wg %9.0f  max wg %9.0f)" % (SEG_WS[q], w.mean(), w.mean(axis=1).min(), w.mean(axis=1).max()))
                     print("   total M %.0f   L %.0f" % (a[:, :4, :4].sum(axis=2).mean(), a[:, 4:, 4:].sum(axis=2).mean()))
+                    if "128x128" in name:      # three roles: weight waves 4-5 (4 barrier waits, 5 write + request, 6 chunk barrier waits, 7 tails), window waves 6-7
+                        for nm, sl in (("weight waves", slice(4, 6)), ("window waves", slice(6, 8))):
+                            print("   %s: " % nm + "  ".join("seg%d %.0f" % (q, a[:, sl, q].mean()) for q in range(4, 8)))
                 elif p == 1:
                     ph = a[:, :, 7].mean()
                     print("%s: phases per wave %.1f" % (name, ph))
