@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=24, help="frames per GPU per step")
     ap.add_argument("--no-vox-ahead", action="store_true",
                     help="voxelize each batch inside its own step instead of one step ahead, beside the previous batch's rulebooks")
     ap.add_argument("--geo-after", type=int, default=6,

@@ -379,6 +379,9 @@ int pvx_sparse_conv_fwd_tb(const void* feat_in, int n_in, int cin, const void* p
 int pvx_conv_out_book(const void* out_index, int n_out, const int* n_out_dev, int batch, const int* in_shape, const int* ksize,
                       const int* stride, const int* padding, const int* dilation, const void* in_index, const int* in_perm,
                       int* coords_out, int* nbr, int n_in, int rcap, void* book, int far_only, void* stream);
+/* HOST: 1 if pvx_sparse_conv_fwd_book takes a call of these sizes (a book-form kernel exists for the shape, the window matches, and the
+ * feature tensors are below the 2 GiB its 32-bit buffer offsets address), else 0: a plan asks before it stores a rulebook far-only. */
+int pvx_sparse_conv_book_form(int n_in, int cin, int cout, int kvol, int n_out, int dtype, int tilebook_rcap);
 int pvx_subm_book(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,
                   const int* perm, const int* dilation, int* nbr_far, int rcap, void* book, void* stream);
 int pvx_sparse_conv_fwd_book(const void* feat_in, int n_in, int cin, const void* prepared_weight, const float* bias,

@@ -124,6 +124,7 @@ SIGNATURES = {
                                        c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "pvx_sparse_conv_fwd_book": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "pvx_sparse_conv_book_form": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "pvx_tilebook_rcap": (c_int, [c_int, c_int, c_int, c_int]),
     "pvx_tilebook_bytes": (c_size_t, [c_int]),
     "pvx_tilebook_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),

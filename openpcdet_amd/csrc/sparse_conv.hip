@@ -809,10 +809,11 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
     }
         PVX_SLAB_SHAPES(X)
 #undef X
-        if (rct != PVX_OK) return rct;
-    } else if (book_only) {
-        return PVX_ERR_RANGE;
-    } else if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
+        if (rct == PVX_OK) { PVX_CHECK_LAUNCH(); return PVX_OK; }
+        if (rct != PVX_ERR_RANGE) return rct;                 // PVX_ERR_RANGE: not taken (> 2 GiB of features): the forms below
+    }
+    if (book_only) return PVX_ERR_RANGE;
+    if (w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) {
         int rcs = PVX_ERR_INVALID;
 #define X(ci, co, rc, sm)                                                                                                     \
     if (cin == ci && cout == co) {                                                                                            \
@@ -823,8 +824,10 @@ static int conv_fwd_impl(const void* feat_in, int n_in, int cin, const void* pre
     }
         PVX_SLAB_SHAPES(X)
 #undef X
-        if (rcs != PVX_OK) return rcs;
-    } else if (w32_shape(cin, cout, kvol, dtype)) {
+        if (rcs == PVX_OK) { PVX_CHECK_LAUNCH(); return PVX_OK; }
+        if (rcs != PVX_ERR_RANGE) return rcs;                 // PVX_ERR_RANGE: > 2 GiB of input features: the gather form below
+    }
+    if (w32_shape(cin, cout, kvol, dtype)) {
         int rc32 = PVX_ERR_INVALID;
 #define X(ci, co)                                                                                                             \
     if (cin == ci && cout == co) {                                                                                            \
@@ -878,6 +881,19 @@ extern "C" int pvx_sparse_conv_fwd_book(const void* feat_in, int n_in, int cin, 
                                         const void* tilebook, int tilebook_rcap, void* stream) {
     return conv_fwd_impl(feat_in, n_in, cin, prepared_weight, bias, nbr_far, kvol, n_out, n_out_dev, cout, dtype, scale, shift, residual,
                          relu, out, tilebook, tilebook_rcap, stream, true);
+}
+
+extern "C" int pvx_sparse_conv_book_form(int n_in, int cin, int cout, int kvol, int n_out, int dtype, int tilebook_rcap) {
+    // does pvx_sparse_conv_fwd_book take this call?  (the conditions of the two book-form branches of conv_fwd_impl and of their launchers)
+    if (n_in <= 0 || n_out <= 0 || tilebook_rcap <= 0 || (dtype != PVX_BF16 && dtype != PVX_F16)) return 0;
+    const unsigned long long feat_bytes = (unsigned long long)n_in * cin * 2, out_bytes = (unsigned long long)n_out * cout * 2;
+    if (feat_bytes >= 0x80000000ull) return 0;
+    if (tilebook_rcap == pvx_st_rcap(cin, cout, kvol, dtype)) return out_bytes < 0x80000000ull ? 1 : 0;
+    if (!(w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype)) || tilebook_rcap != tilebook_rcap_of(cin, cout, kvol, dtype)) return 0;
+#define X(ci, co, rc, sm) if (cin == ci && cout == co) return (sm == 0 || sm == 3) ? 1 : 0;
+    PVX_SLAB_SHAPES(X)
+#undef X
+    return 0;
 }
 
 extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {

@@ -325,7 +325,9 @@ class HotPathEngine:
                         if rcap_s > 0:
                             book_s = torch.empty(L.pvx_tilebook_bytes(nxt.cap), dtype=torch.uint8, device=dev)
                             self._books[(nbr.data_ptr(), rcap_s)] = book_s
-                            a2b = a2 + (cur.cap, rcap_s, _lib.ptr(book_s), 1 if self.far_only else 0)
+                            far_s = self.far_only and bool(L.pvx_sparse_conv_book_form(cur.cap, cin_cur, conv.out_channels, kvol, nxt.cap,
+                                                                                       self.code, rcap_s))
+                            a2b = a2 + (cur.cap, rcap_s, _lib.ptr(book_s), 1 if far_s else 0)
                             self.ops.append(("conv_out_rulebook",
                                              lambda st, a=a2b: _lib.check(L.pvx_conv_out_book(*a, st), "pvx_conv_out_book")))
                         else:
@@ -334,7 +336,7 @@ class HotPathEngine:
                         # the input level's index has had its last reader (its submanifold rulebooks were built before this conv)
                         add_unset(cur, cur.coords)     # (level 0: the rows in key order after pvx_sort_sites mark the same cells)
                         cur_feat, cin_cur = add_conv(spec, cur, nxt, cur_feat, cin_cur, nbr, None, avoid=())
-                        if rcap_s > 0 and self.far_only:
+                        if rcap_s > 0 and far_s:
                             r = self.conv_records[-1]
                             assert r["rcap"] == rcap_s and r["book"] is book_s
                             r["far_only"] = True
@@ -371,11 +373,14 @@ class HotPathEngine:
                 self.ops.append(("dense", lambda st, a=ad: _lib.check(L.pvx_sparse_to_dense(*a, st), "pvx_sparse_to_dense")))
         # the last level's index is read by the line-form dense pass on the main stream: its un-set follows there
         add_unset(cur, cur.coords, name="index_unset_main")
+        def book_form(r):
+            return bool(L.pvx_sparse_conv_book_form(r["level_in"].cap, r["cin"], r["cout"], r["kvol"], r["level_out"].cap, self.code, r["rcap"]))
+
         if self.far_only:
             # rulebooks written together with their book (pvx_subm_rulebook_tb) whose every reader uses that very book
             for ptr, (at, af, rcap) in self._fused_books.items():
                 readers = [r for r in self.conv_records if r["nbr"].data_ptr() == ptr]
-                if readers and all(r["rcap"] == rcap and r["book"] is self._books[(ptr, rcap)] for r in readers):
+                if readers and all(r["rcap"] == rcap and r["book"] is self._books[(ptr, rcap)] and book_form(r) for r in readers):
                     self.ops[at] = ("subm_rulebook", lambda st, a=af: _lib.check(L.pvx_subm_book(*a, st), "pvx_subm_book"))
                     for r in readers:
                         r["far_only"] = True

@@ -351,3 +351,10 @@ def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
     assert rc == -4
     rc, _ = _run_conv_entry("pvx_sparse_conv_fwd_book", dev, feat, w, nbr_far, n_dev, cin, cout, code, None, 0)
     assert rc == -1
+    # the host query a plan uses before it stores a rulebook far-only
+    assert L.pvx_sparse_conv_book_form(cap, 64, 64, 27, cap, code, rcap) == 1
+    assert L.pvx_sparse_conv_book_form(cap, 64, 64, 27, cap, code, rcap + 1) == 0
+    assert L.pvx_sparse_conv_book_form(cap, 128, 128, 27, cap, code, rcap) == 0
+    assert L.pvx_sparse_conv_book_form(1 << 24, 64, 64, 27, cap, code, rcap) == 0        # 2 GiB of input rows: 32-bit buffer offsets
+    assert L.pvx_sparse_conv_book_form(cap, 16, 32, 27, cap, code, L.pvx_tilebook_rcap(16, 32, 27, code)) == 1
+    assert L.pvx_sparse_conv_book_form(cap, 64, 64, 27, cap, 0, rcap) == 0
