@@ -118,7 +118,7 @@ class _SyncBNAct(Function):
 
 def _sync_group(bn):
     """the process group a SyncBatchNorm module reduces over, or None when it would not synchronise (torch falls back to plain
-    batch_norm then: not training, no process group, world size 1 is still synchronised here -- a one-rank all-reduce)"""
+    batch_norm then: not training, no process group; a group of ONE rank is handled by bn_act without a collective)"""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return None
@@ -150,5 +150,15 @@ def bn_act(x, bn, residual=None, relu=True):
         bn.num_batches_tracked.add_(1)
     args = (x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, rm, rv, residual, bn.eps, bn.momentum, relu)
     if type(bn) is nn.SyncBatchNorm:
-        return _SyncBNAct.apply(*args, _sync_group(bn))
+        group = _sync_group(bn)
+        import torch.distributed as dist
+        if dist.get_world_size(group) > 1:
+            return _SyncBNAct.apply(*args, group)
+        # a group of one rank: the statistics are this rank's own, no collective (torch.nn.SyncBatchNorm takes its plain batch_norm
+        # path in that case too: need_sync = world_size > 1); the choice depends on the group only, so every rank makes the same one
+        if x.shape[0] <= 1:
+            y = bn(x)
+            if residual is not None:
+                y = y + residual
+            return torch.relu(y) if relu else y
     return _BNAct.apply(*args)
