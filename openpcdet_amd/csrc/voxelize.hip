@@ -51,15 +51,29 @@ __device__ __forceinline__ bool cell_of(float p, float lo, float vs, int g, int&
     return true;
 }
 
+// Frame-to-XCD mapping of the frame-parallel kernels: a 1-D grid in which block L runs on XCD L % 8 (the dispatcher deals workgroups to
+// the eight XCDs in turn), so frame f = (L % 8) + 8 * ((L / 8) / nb) keeps all its blocks -- and its hash table, 4 MB at nuScenes size,
+// its lists and its slot maps -- in ONE XCD's L2 instead of bouncing between eight (bucket kernel 248 -> 148 us, whole voxelizer
+// 660 -> 532 us at batch 16: profiles/r03_voxelizer.txt).  Used for batches of whole groups of eight frames.
+struct FrameBlock { int frame, block; bool ok; };
+__device__ __forceinline__ FrameBlock frame_block(int nb, int frames, int xcd_map) {
+    if (!xcd_map) return { (int)blockIdx.y, (int)blockIdx.x, true };
+    const int L = blockIdx.x, j = L >> 3;
+    const int f = (L & 7) + 8 * (j / nb);
+    return { f, j % nb, f < frames };
+}
+
 // Every kernel below runs one frame per blockIdx.y: frame f uses points + f * n * c, its own hash table
 // (table / vid_of_slot + f * table slots), slot_of_point + f * n, block_sums + f * nb, lists + f * max_voxels * T.
 // The single-frame entry points launch with gridDim.y == 1.
 __global__ __launch_bounds__(kBlk) void vox_insert_kernel(const float* __restrict__ pts, int n, int c, VoxGeom g,
                                                            unsigned long long* table, unsigned cap_mask,
-                                                           int* __restrict__ slot_of_point) {
-    const int i = blockIdx.x * kBlk + threadIdx.x;
+                                                           int* __restrict__ slot_of_point, int nb, int frames, int xcd_map) {
+    const FrameBlock fbk = frame_block(nb, frames, xcd_map);
+    if (!fbk.ok) return;
+    const int i = fbk.block * kBlk + threadIdx.x;
     if (i >= n) return;
-    const size_t f = blockIdx.y;
+    const size_t f = fbk.frame;
     pts += f * (size_t)n * c; table += f * ((size_t)cap_mask + 1);
     slot_of_point += f * (size_t)n;
     const float* p = pts + (size_t)i * c;
@@ -111,11 +125,14 @@ constexpr int kFirstBit = 0x40000000;
 
 __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(int* __restrict__ slot_of_point,
                                                                     const unsigned long long* __restrict__ table, int n,
-                                                                    size_t table_slots, int* __restrict__ block_sums) {
+                                                                    size_t table_slots, int* __restrict__ block_sums, int nb, int frames,
+                                                                    int xcd_map) {
     __shared__ int wave_sums[kScanBlk / 64];
-    const size_t f = blockIdx.y;
-    slot_of_point += f * (size_t)n; table += f * table_slots; block_sums += f * gridDim.x;
-    const int i = blockIdx.x * kScanBlk + threadIdx.x;
+    const FrameBlock fbk = frame_block(nb, frames, xcd_map);
+    if (!fbk.ok) return;                                       // the whole workgroup
+    const size_t f = fbk.frame;
+    slot_of_point += f * (size_t)n; table += f * table_slots; block_sums += f * nb;
+    const int i = fbk.block * kScanBlk + threadIdx.x;
     bool flag = false;
     if (i < n) {
         const int s = slot_of_point[i];
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(kScanBlk) void vox_count_first_kernel(int* __restri
     }
     int total;
     block_rank(flag, wave_sums, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) block_sums[fbk.block] = total;
 }
 
 // exclusive scan of each frame's nb block sums (block_sums -> block_offsets), ONE workgroup per frame; per-frame voxel count ->
@@ -200,16 +217,18 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(int* __restrict__ 
                                                                int* __restrict__ coords_zyx, int* __restrict__ coords_bzyx,
                                                                int batch_idx, const int* __restrict__ row_base_dev,
                                                                int row_capacity, int* __restrict__ lists, int T,
-                                                               int* __restrict__ point_to_voxel) {
+                                                               int* __restrict__ point_to_voxel, int nb, int frames, int xcd_map) {
     __shared__ int wave_sums[kScanBlk / 64];
-    const size_t f = blockIdx.y;
+    const FrameBlock fbk = frame_block(nb, frames, xcd_map);
+    if (!fbk.ok) return;                                       // the whole workgroup
+    const size_t f = fbk.frame;
     lists += f * (size_t)max_voxels * T;
     if (point_to_voxel) point_to_voxel += f * (size_t)n;
     slot_of_point += f * (size_t)n; table += f * table_slots; vid_of_slot += f * table_slots;
-    block_offsets += f * gridDim.x;
+    block_offsets += f * nb;
     if (coords_zyx) coords_zyx += f * (size_t)max_voxels * 3;
-    if (gridDim.y > 1) batch_idx = (int)f;
-    const int i = blockIdx.x * kScanBlk + threadIdx.x;
+    if (frames > 1) batch_idx = (int)f;
+    const int i = fbk.block * kScanBlk + threadIdx.x;
     bool flag = false;
     int s = -1;
     unsigned long long word = 0;
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(int* __restrict__ 
         if (s >= 0 && (s & kFirstBit)) { s &= ~kFirstBit; flag = true; word = table[s]; }
     }
     int total;
-    const int rank = block_offsets[blockIdx.x] + block_rank(flag, wave_sums, total);
+    const int rank = block_offsets[fbk.block] + block_rank(flag, wave_sums, total);
     if (flag) {
         vid_of_slot[s] = rank;
         slot_of_point[i] = kFirstDone;
@@ -240,10 +259,13 @@ __global__ __launch_bounds__(kScanBlk) void vox_assign_kernel(int* __restrict__ 
 
 __global__ __launch_bounds__(kBlk) void vox_bucket_kernel(const int* __restrict__ slot_of_point,
                                                            const int* __restrict__ vid_of_slot, int n, size_t table_slots, int T,
-                                                           int max_voxels, int* lists, int* __restrict__ point_to_voxel) {
-    const int i = blockIdx.x * kBlk + threadIdx.x;
+                                                           int max_voxels, int* lists, int* __restrict__ point_to_voxel, int nb, int frames,
+                                                           int xcd_map) {
+    const FrameBlock fbk = frame_block(nb, frames, xcd_map);
+    if (!fbk.ok) return;
+    const int i = fbk.block * kBlk + threadIdx.x;
     if (i >= n) return;
-    const size_t f = blockIdx.y;
+    const size_t f = fbk.frame;
     slot_of_point += f * (size_t)n; vid_of_slot += f * table_slots; lists += f * (size_t)max_voxels * T;
     if (point_to_voxel) point_to_voxel += f * (size_t)n;
     const int s = slot_of_point[i];
@@ -355,9 +377,11 @@ __global__ __launch_bounds__(kBlk) void vox_gather_rows_kernel(const float* __re
                                                                 float* __restrict__ voxels, int* __restrict__ num_per_voxel,
                                                                 void* __restrict__ mean, int mean_stride, int mean_dtype,
                                                                 const int* __restrict__ row_base_dev, int row_capacity,
-                                                                int vector_rows) {
-    const int v = blockIdx.x * kBlk + threadIdx.x;
-    const size_t f = blockIdx.y;
+                                                                int vector_rows, int nb, int frames, int xcd_map) {
+    const FrameBlock fbk = frame_block(nb, frames, xcd_map);
+    if (!fbk.ok) return;
+    const int v = fbk.block * kBlk + threadIdx.x;
+    const size_t f = fbk.frame;
     if (v >= num_voxels[f]) return;
     pts += f * (size_t)n * c; lists += f * (size_t)max_voxels * T;
     if (voxels) voxels += f * (size_t)max_voxels * T * c;
@@ -518,28 +542,35 @@ int voxelize_impl(const float* points, int frames, int n, int c, const float* vs
     PVX_CHECK_HIP(hipMemsetAsync(w.lists, 0x7f, F * (size_t)max_voxels * T * sizeof(int), st));
     const int nb_pts = PVX_CDIV(n, kBlk), nb_scan = PVX_CDIV(n, kScanBlk);
     const int* row_bases = o.batch ? w.row_bases : o.row_base_dev;
-    hipLaunchKernelGGL(vox_insert_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, points, n, c, g, w.table,
-                       (unsigned)(cap - 1), w.slot_of_point);
+    // frame-to-XCD mapping (frame_block above): whole groups of eight frames only, else some XCDs would idle; PVX_VOX_XCD=0: A/B switch
+    static const int xcd_env = [] { const char* e = getenv("PVX_VOX_XCD"); return e ? atoi(e) : 1; }();
+    const int xcd_map = xcd_env && frames % 8 == 0 ? 1 : 0;
+    const dim3 grid_pts = xcd_map ? dim3((unsigned)(nb_pts * ((frames + 7) / 8 * 8))) : dim3(nb_pts, frames);
+    hipLaunchKernelGGL(vox_insert_kernel, grid_pts, dim3(kBlk), 0, st, points, n, c, g, w.table,
+                       (unsigned)(cap - 1), w.slot_of_point, nb_pts, frames, xcd_map);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_count_first_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
-                       w.block_sums);
+    const dim3 grid_scan = xcd_map ? dim3((unsigned)(nb_scan * ((frames + 7) / 8 * 8))) : dim3(nb_scan, frames);
+    hipLaunchKernelGGL(vox_count_first_kernel, grid_scan, dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
+                       w.block_sums, nb_scan, frames, xcd_map);
     PVX_CHECK_LAUNCH();
     hipLaunchKernelGGL(vox_scan_blocks_kernel, dim3(frames), dim3(kScanBlk), 0, st, w.block_sums, w.block_offsets, nb_scan, frames, max_voxels, o.num_voxels,
                        o.batch ? w.row_bases : nullptr, o.row_capacity, o.batch ? o.row_end_dev : nullptr);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_assign_kernel, dim3(nb_scan, frames), dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
+    hipLaunchKernelGGL(vox_assign_kernel, grid_scan, dim3(kScanBlk), 0, st, w.slot_of_point, w.table, n, cap,
                        w.block_offsets, g, max_voxels, w.vid_of_slot, o.coords_zyx, o.coords_bzyx, o.batch_idx, row_bases,
-                       o.row_capacity, w.lists, T, o.point_to_voxel);
+                       o.row_capacity, w.lists, T, o.point_to_voxel, nb_scan, frames, xcd_map);
     PVX_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vox_bucket_kernel, dim3(nb_pts, frames), dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,
-                       max_voxels, w.lists, o.point_to_voxel);
+    hipLaunchKernelGGL(vox_bucket_kernel, grid_pts, dim3(kBlk), 0, st, w.slot_of_point, w.vid_of_slot, n, cap, T,
+                       max_voxels, w.lists, o.point_to_voxel, nb_pts, frames, xcd_map);
     PVX_CHECK_LAUNCH();
     static const bool rows_form = [] { const char* e = getenv("PVX_VOX_GATHER_ROWS"); return !(e && e[0] == '0'); }();   // A/B switch
     if (rows_form && T <= kRowsT && c <= kRowsC) {
         const int vector_rows = o.mean && o.mean_dtype != PVX_F32 && o.mean_stride == 16 && ((uintptr_t)o.mean & 15) == 0;
-        hipLaunchKernelGGL(vox_gather_rows_kernel, dim3((unsigned)PVX_CDIV(max_voxels, kBlk), frames), dim3(kBlk), 0, st, points, n, c,
+        const int nb_vox = PVX_CDIV(max_voxels, kBlk);
+        const dim3 grid_vox = xcd_map ? dim3((unsigned)(nb_vox * ((frames + 7) / 8 * 8))) : dim3((unsigned)nb_vox, frames);
+        hipLaunchKernelGGL(vox_gather_rows_kernel, grid_vox, dim3(kBlk), 0, st, points, n, c,
                            T, w.lists, max_voxels, o.num_voxels, o.voxels, o.num_points_per_voxel, o.mean, o.mean_stride,
-                           o.mean_dtype, row_bases, o.row_capacity, vector_rows);
+                           o.mean_dtype, row_bases, o.row_capacity, vector_rows, nb_vox, frames, xcd_map);
     } else {
         const long long work = (long long)max_voxels * o.mean_stride;
         hipLaunchKernelGGL(vox_gather_kernel, dim3((unsigned)PVX_CDIV(work, (long long)kBlk), frames), dim3(kBlk), 0, st, points, n, c,
