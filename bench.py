@@ -119,7 +119,7 @@ def conv_kernel_name(cin, cout, kvol):
     if kvol == 27 and (cin, cout) in engine.HotPathEngine.TILEBOOK_SHAPES and os.environ.get("PVX_ENGINE_TILEBOOK", "1") == "1":
         if (cin, cout) == (32, 32) and os.environ.get("PVX_CONV_ROLL", "1") != "0":
             return "sparse_conv_slab_roll_kernel<bf16,%d,%d>" % (cin, cout)
-        if (cin, cout) == (16, 16):
+        if (cin, cout) in ((16, 16), (16, 32)):
             return "sparse_conv_slab_tb_kernel<bf16,%d,%d>" % (cin, cout)
     if kvol == 27 and (cin, cout) in ((16, 16), (16, 32), (32, 32), (32, 64), (64, 64)):
         return "sparse_conv_slab_kernel<bf16,%d,%d>" % (cin, cout)
@@ -450,8 +450,8 @@ def main():
         for (lname, n_rows, pairs, f), rec in zip(per_layer, eng.conv_records):
             kname = conv_kernel_name(rec["cin"], rec["cout"], rec["kvol"])
             n_in = min(int(rec["level_in"].n_dev.item()), rec["level_in"].cap)
-            byts = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 * (2 if rec["residual"] else 1) + rec["kvol"] * n_rows * 4 + \
-                rec["kvol"] * rec["cin"] * rec["cout"] * 2
+            byts = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 * (2 if rec["residual"] else 1) + \
+                rec["kvol"] * n_rows * (2 if rec["rcap"] > 0 else 4) + rec["kvol"] * rec["cin"] * rec["cout"] * 2    # (u16 codes where a tile book is read)
             # SURVEY.md 8d's compulsory bytes: features in + features out + weights, no rulebook, no residual
             comp = n_in * rec["cin"] * 2 + n_rows * rec["cout"] * 2 + rec["kvol"] * rec["cin"] * rec["cout"] * 2
             us = sum(a.elapsed_time(b) for a, b in ev[lname]) / passes * 1e3
@@ -514,11 +514,17 @@ def main():
         n_pts = sum(int(f.shape[0]) for f in frames[:B])
         m0 = rows[0]
         vox_bytes = n_pts * 4 * cfg["C"] + n_pts * 4 + m0 * (16 + 4 * cfg["C"])
-        rule_bytes = 0
-        for li, n_l in enumerate(rows[:-1]):
-            rule_bytes += n_l * 16 + 27 * n_l * 4                       # one submanifold rulebook per level
-            n_next = rows[li + 1]
-            rule_bytes += n_l * 16 + n_next * 16 + (27 if li < 3 else 3) * n_next * 4    # strided conv into the next level
+        # rulebooks as the plan stores them: coordinates read (and, for a strided conv, written) + per output site either the int32 table
+        # (4 B x K) or, where every reader goes through one tile book, the book's u16 codes (2 B x 27; the far entries are a few per cent)
+        rule_bytes, seen = 0, set()
+        for rec in eng.conv_records:
+            if rec["nbr"].data_ptr() in seen:
+                continue
+            seen.add(rec["nbr"].data_ptr())
+            n_o = min(int(rec["level_out"].n_dev.item()), rec["level_out"].cap)
+            n_i = min(int(rec["level_in"].n_dev.item()), rec["level_in"].cap)
+            per_site = 27 * 2 if rec["far_only"] else rec["kvol"] * 4 + (27 * 2 if rec["rcap"] > 0 else 0)
+            rule_bytes += n_o * 16 + (0 if rec["subm"] else n_i * 16) + per_site * n_o
         hbm = {"peak_GBps": 8000.0,
                "voxelize": {"bytes": vox_bytes, "GBps": round(vox_bytes / (vox_ms * 1e-3) / 1e9, 1)},
                "rulebook": {"bytes": rule_bytes, "GBps": round(rule_bytes / (rule_ms * 1e-3) / 1e9, 1)}}
