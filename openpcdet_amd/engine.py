@@ -409,14 +409,29 @@ class HotPathEngine:
                                              self.cin0, self.code, _lib.ptr(self.num_voxels), _lib.ptr(lvl.n_dev),
                                              _lib.ptr(self.vox_ws), self.vox_ws.numel(), st), "pvx_voxelize_mean_batch")
 
+    def _begin_ops(self):
+        """the clean-index protocol (level indices zero between forwards) holds only if every forward enqueued ALL its launches, the
+        un-sets included: a forward that raised half-way leaves marked words behind, so the next one zero-fills the indices first"""
+        if self.clean_index and getattr(self, "_ops_open", False):
+            torch.cuda.synchronize(self.device)
+            for lvl in self.levels:
+                lvl.index.zero_()
+            torch.cuda.synchronize(self.device)
+        self._ops_open = True
+
+    def _end_ops(self):
+        self._ops_open = False
+
     def backbone(self, st=None, hook=None):
         st = _lib.stream() if st is None else st
+        self._begin_ops()
         if hook is None:
             for _, fn in self.ops:
                 fn(st)
         else:
             for name, fn in self.ops:
                 hook(name, lambda: fn(st))
+        self._end_ops()
 
     _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook", "index_unset")
 
@@ -471,6 +486,7 @@ class HotPathEngine:
                     self.voxelize(g)
                 pending = self._geo_events[0]
                 pending.record(geo)
+                self._begin_ops()
                 i = 1
                 n_conv = 0
                 if mark_after is not None and getattr(self, "mark", None) is None:
@@ -504,6 +520,7 @@ class HotPathEngine:
                                 self.mark2.record(main)
                 if pending is not None:
                     main.wait_event(pending)
+                self._end_ops()
                 self._done.record(main)
         if self.want_dense:
             d = self.dense

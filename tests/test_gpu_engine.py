@@ -406,3 +406,39 @@ def test_voxelize_ahead_and_shared_geometry_stream(cuda_device):
             got = plan.forward(overlap=True, pipelined=True, prevoxelized=True).clone()
             torch.cuda.synchronize()
             assert torch.equal(got, w), (rnd, plan is eng)
+
+
+def test_interrupted_forward_does_not_poison_the_next(cuda_device):
+    """the plan keeps its level indices zero between forwards by un-setting what it set; a forward that raises half-way (here: a
+    launch replaced by one that fails after the level-0 index was built) must not leave marked cells for the next forward"""
+    cfg = SMALL
+    frames = [synth.config_cloud("nuscenes_centerpoint", seed, n_points=12000) for seed in (61, 62)]
+    net = make_backbone(backbones.VoxelResBackBone8x, cfg, 17, cuda_device)
+    eng = engine.HotPathEngine(net, 2, cfg["range"], cfg["voxel"], cfg["T"], cfg["max_voxels"], cfg["C"], 12000, dtype=torch.bfloat16,
+                               device=cuda_device)
+    assert eng.clean_index
+    dev_frames = [torch.from_numpy(f).to(cuda_device) for f in frames]
+    eng.load_points(dev_frames)
+    want = eng.forward(overlap=False).clone()
+    torch.cuda.synchronize()
+    assert all(int(l.index.count_nonzero().item()) == 0 for l in eng.levels)        # every index left zero
+    at = next(i for i, (name, _) in enumerate(eng.ops) if name.startswith("conv"))
+    saved = eng.ops[at]
+
+    def boom(st):
+        raise RuntimeError("injected")
+    eng.ops[at] = (saved[0], boom)
+    other = [torch.from_numpy(synth.config_cloud("nuscenes_centerpoint", 63, n_points=9000)).to(cuda_device) for _ in range(2)]
+    eng.load_points(other)
+    with pytest.raises(RuntimeError, match="injected"):
+        eng.forward(overlap=False)
+    torch.cuda.synchronize()
+    assert int(eng.levels[0].index.count_nonzero().item()) > 0                      # the interrupted forward left its marks
+    eng.ops[at] = saved
+    eng.load_points(dev_frames)
+    got = eng.forward(overlap=False).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    got2 = eng.forward(overlap=True).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want)
