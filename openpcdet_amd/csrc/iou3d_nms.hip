@@ -241,6 +241,153 @@ __global__ __launch_bounds__(kBlock) void nms_scan_kernel(const unsigned long lo
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Mask and scan in one kernel, one workgroup per problem, for MANY SMALL problems (the per-head NMS of a batch: a few
+// hundred boxes each, a hundred or more problems).  The greedy scan consults row i's suppression word only when row i is
+// kept, so only those rows need their IoUs: per 64-box chunk, (1) the diagonal tile for the rows still alive, (2) the
+// in-chunk scan by wave 0, (3) the chunk's KEPT rows against every later column that is still alive.  Rows and columns
+// that are already suppressed are skipped -- a suppressed row's word is never read and OR-ing a bit over a set one
+// changes nothing -- so the keep list is the one nms_mask_kernel + nms_scan_kernel produce, bit for bit, at a fraction
+// of the pair tests (most boxes of a head's top-k are suppressed by a handful of kept ones).  No mask leaves the CU.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLazyMax = 1024;           // boxes per problem: their prepared records fill 64 KiB of LDS
+constexpr int kLazyQueue = 4096;         // candidate pairs of one pass
+constexpr int kLazyMinSegments = 16;     // fewer problems than this: the tiled mask kernel spreads one problem over many CUs
+
+template <int NORMAL>
+__global__ __launch_bounds__(kBlock) void nms_lazy_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                                           int n_host, int n_cap, float thresh, long long* __restrict__ keep,
+                                                           int* __restrict__ num_keep, const int* __restrict__ order,
+                                                           long long* __restrict__ sel, int post_max) {
+    __shared__ PvxBoxRec rec[kLazyMax];
+    __shared__ VertexScratch vs;
+    __shared__ unsigned long long remv[kLazyMax / 64];
+    __shared__ unsigned long long words[64];
+    __shared__ unsigned int queue[kLazyQueue];
+    __shared__ int qcount;
+    __shared__ int kept_in_chunk[64];
+    __shared__ int kept_count;
+    float* raw = reinterpret_cast<float*>(rec);            // NORMAL: the 7 floats of each box instead of its record
+
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    int n = counts ? counts[seg] : n_host;
+    n = n < 0 ? 0 : (n > n_cap ? n_cap : n);
+    const int cb = PVX_CDIV(n, 64);
+    const float* seg_boxes = boxes + (size_t)seg * n_cap * 7;
+    long long* seg_keep = keep + (size_t)seg * n_cap;
+    if (NORMAL) {
+        for (int e = tid; e < n * 7; e += kBlock) raw[e] = seg_boxes[e];
+    } else {
+        for (int i = tid; i < n; i += kBlock) pvx_box_prepare(seg_boxes + (size_t)i * 7, rec[i]);
+    }
+    if (tid < kLazyMax / 64) remv[tid] = 0ull;
+
+    int total = 0;
+    for (int c = 0; c < cb; c++) {
+        __syncthreads();   // boxes staged; remv[c] final; the previous chunk's kept list and queue consumed
+        if (tid < 64) words[tid] = 0ull;
+        if (tid == 0) qcount = 0;
+        __syncthreads();
+        const int base = c * 64;
+        const int n_r = (n - base) < 64 ? (n - base) : 64;
+        const unsigned long long dead = remv[c];
+        // (1) diagonal tile: alive row x later alive column
+        for (int p = tid; p < 64 * 64; p += kBlock) {
+            const int rt = p >> 6, ct = p & 63;
+            if (rt >= n_r || ct >= n_r || ct <= rt) continue;
+            if (((dead >> rt) | (dead >> ct)) & 1ull) continue;
+            if (NORMAL) {
+                if (pvx_iou_normal(raw + (base + rt) * 7, raw + (base + ct) * 7) > thresh) atomicOr(&words[rt], 1ull << ct);
+            } else {
+                const float ddx = rec[base + rt].cx - rec[base + ct].cx, ddy = rec[base + rt].cy - rec[base + ct].cy;
+                const float reach = (rec[base + rt].rad + rec[base + ct].rad) * 1.0001f + 0.05f;
+                if (thresh >= 0.f && ddx * ddx + ddy * ddy > reach * reach) continue;   // far apart: overlap exactly 0
+                queue[atomicAdd(&qcount, 1)] = (unsigned)p;
+            }
+        }
+        if (!NORMAL) {
+            __syncthreads();
+            const int nq = qcount;
+            for (int q = tid; q < nq; q += kBlock) {
+                const int p = (int)queue[q], rt = p >> 6, ct = p & 63;
+                const PvxBoxRec A = rec[base + rt], B = rec[base + ct];
+                const float v = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock));
+                if (v > thresh) atomicOr(&words[rt], 1ull << ct);
+            }
+        }
+        __syncthreads();
+        // (2) the in-chunk dependency chain, as nms_scan_kernel resolves it
+        if (tid < 64) {
+            const unsigned long long diag = words[tid];
+            unsigned long long cur = dead;
+            unsigned long long kept = 0ull;
+            for (int k = 0; k < n_r; k++) {
+                const unsigned long long dk = __shfl(diag, k);
+                if (!((cur >> k) & 1ull)) { kept |= 1ull << k; cur |= dk; }
+            }
+            if ((kept >> tid) & 1ull) {
+                const int pos = __popcll(kept & ((1ull << tid) - 1ull));
+                kept_in_chunk[pos] = tid;
+                seg_keep[total + pos] = (long long)(base + tid);
+            }
+            if (tid == 0) kept_count = __popcll(kept);
+        }
+        __syncthreads();
+        const int kc = kept_count;
+        total += kc;
+        if (kc == 0 || base + 64 >= n) continue;           // workgroup-uniform
+        // (3) kept rows of this chunk x every later alive column, in passes whose pairs fit the queue
+        const int step = (kLazyQueue / kc) & ~63;          // kc <= 64, so at least one column tile per pass
+        for (int c0 = base + 64; c0 < n; c0 += step) {
+            const int ncol = (n - c0) < step ? (n - c0) : step;
+            if (!NORMAL) {
+                if (tid == 0) qcount = 0;
+                __syncthreads();
+            }
+            for (int p = tid; p < kc * ncol; p += kBlock) {
+                const int q = p / ncol, col = c0 + (p - q * ncol);
+                if ((remv[col >> 6] >> (col & 63)) & 1ull) continue;   // NORMAL: may miss a bit set this pass -- one test more, same result
+                const int row = base + kept_in_chunk[q];
+                if (NORMAL) {
+                    if (pvx_iou_normal(raw + row * 7, raw + col * 7) > thresh) atomicOr(&remv[col >> 6], 1ull << (col & 63));
+                } else {
+                    const float ddx = rec[row].cx - rec[col].cx, ddy = rec[row].cy - rec[col].cy;
+                    const float reach = (rec[row].rad + rec[col].rad) * 1.0001f + 0.05f;
+                    if (thresh >= 0.f && ddx * ddx + ddy * ddy > reach * reach) continue;
+                    queue[atomicAdd(&qcount, 1)] = ((unsigned)row << 16) | (unsigned)col;
+                }
+            }
+            if (!NORMAL) {
+                __syncthreads();
+                const int nq = qcount;
+                for (int q = tid; q < nq; q += kBlock) {
+                    const unsigned e = queue[q];
+                    const int row = (int)(e >> 16), col = (int)(e & 0xffffu);
+                    const PvxBoxRec A = rec[row], B = rec[col];
+                    const float v = pvx_iou_from_overlap(A, B, pvx_overlap(A, B, vs.x + tid, vs.y + tid, vs.a + tid, kBlock));
+                    if (v > thresh) atomicOr(&remv[col >> 6], 1ull << (col & 63));
+                }
+                __syncthreads();                           // every thread has read qcount before the next pass resets it
+            }
+        }
+    }
+    if (!order) {
+        if (tid == 0) num_keep[seg] = total;
+        return;
+    }
+    // select epilogue, as nms_scan_kernel's
+    __syncthreads();
+    const int* seg_order = order + (size_t)seg * n_cap;
+    const int lim = total < post_max ? total : post_max;
+    for (int j = tid; j < post_max; j += kBlock) sel[(size_t)seg * post_max + j] = seg_order[j < lim ? (int)seg_keep[j] : 0];
+    if (tid == 0) num_keep[seg] = lim;
+}
+
+static bool nms_lazy_takes(int n_cap, int segments) {
+    static const bool on = [] { const char* e = getenv("PVX_NMS_LAZY"); return !(e && e[0] == '0'); }();   // A/B switch
+    return on && n_cap <= kLazyMax && segments >= kLazyMinSegments;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Front end of one NMS problem per workgroup: keys = (score descending, index ascending) of the boxes with
 // index < counts[seg] and score >= score_thresh, bitonic-sorted in LDS (P = power of two >= n_cap keys of 8 bytes);
 // the best min(valid, pre_max) boxes are gathered in that order, `order` keeps their original indices.
@@ -350,6 +497,16 @@ extern "C" size_t pvx_nms_workspace_bytes(int n_cap, int segments) {
 // mask kernel + scan kernel over a caller-resolved mask buffer: shared by the workspace entry points and pvx_nms_static
 static int nms_run(const float* boxes, const int* counts, int segments, int n_cap, int cb_cap, float thresh, int normal,
                    int64_t* keep, int* num_keep, unsigned long long* mask, hipStream_t st) {
+    if (nms_lazy_takes(n_cap, segments)) {
+        if (normal)
+            hipLaunchKernelGGL(nms_lazy_kernel<1>, dim3(segments), dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, thresh,
+                               (long long*)keep, num_keep, (const int*)nullptr, (long long*)nullptr, 0);
+        else
+            hipLaunchKernelGGL(nms_lazy_kernel<0>, dim3(segments), dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, thresh,
+                               (long long*)keep, num_keep, (const int*)nullptr, (long long*)nullptr, 0);
+        PVX_CHECK_LAUNCH();
+        return PVX_OK;
+    }
     dim3 grid(cb_cap, cb_cap, segments);
     if (normal)
         hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, boxes, counts, n_cap, n_cap, cb_cap, thresh, mask);
@@ -410,6 +567,16 @@ extern "C" int pvx_nms_select_batched(const float* boxes, int box_stride, const 
     hipLaunchKernelGGL(nms_sort_gather_kernel, dim3(segments), dim3(kSortBlock), lds, st, boxes, box_stride, scores, counts, n_cap, P,
                        score_thresh, pre_max, sorted, order, eff);
     PVX_CHECK_LAUNCH();
+    if (nms_lazy_takes(n_cap, segments)) {
+        if (normal)
+            hipLaunchKernelGGL(nms_lazy_kernel<1>, dim3(segments), dim3(kBlock), 0, st, sorted, eff, n_cap, n_cap, nms_thresh, keep,
+                               num_selected, (const int*)order, (long long*)selected, post_max);
+        else
+            hipLaunchKernelGGL(nms_lazy_kernel<0>, dim3(segments), dim3(kBlock), 0, st, sorted, eff, n_cap, n_cap, nms_thresh, keep,
+                               num_selected, (const int*)order, (long long*)selected, post_max);
+        PVX_CHECK_LAUNCH();
+        return PVX_OK;
+    }
     dim3 grid(cb_cap, cb_cap, segments);
     if (normal)
         hipLaunchKernelGGL(nms_mask_kernel<1>, grid, dim3(kBlock), 0, st, sorted, eff, n_cap, n_cap, cb_cap, nms_thresh, mask);

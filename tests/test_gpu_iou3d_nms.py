@@ -205,6 +205,38 @@ def test_nms_select_vs_oracle(cuda_device, cap, S):
         assert np.array_equal(sel[s, :int(num[s])].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("cap,spread,thresh", [(500, 9.0, 0.2), (1000, 60.0, 0.5), (1024, 3.0, 0.1), (1024, 200.0, 0.7),
+                                               (130, 5.0, -1.0), (1025, 12.0, 0.2)])
+def test_nms_many_small_problems(cuda_device, cap, spread, thresh):
+    """16 or more problems of at most 1024 boxes go through the one-kernel form (mask and scan fused, IoUs only for rows that are kept);
+    anything else through the tiled mask + scan.  Both must give the oracle's keep lists, and each other's: every segment is also run
+    alone (one problem = the tiled form).  Spreads from 'everything overlaps' to 'nothing does' (kept rows per 64-box chunk from 1 to
+    64: the column passes split), a negative threshold (every pair suppresses), ragged counts, rotated and axis-aligned."""
+    rng = np.random.default_rng(700 + cap + int(spread))
+    S = 18
+    boxes = np.zeros((S, cap, 7), np.float32)
+    scores = np.zeros((S, cap), np.float32)
+    counts = np.array(([cap, cap - 1, 0, 1, 64, 65, cap // 2, 129, 63] * 2)[:S], np.int32)
+    for s in range(S):
+        boxes[s] = _rand_boxes(rng, cap, spread * (1 + 0.1 * s))
+        scores[s] = rng.permutation(cap).astype(np.float32)
+    tb, ts, tc = (torch.from_numpy(x).to(cuda_device) for x in (boxes, scores, counts))
+    for normal in (False, True):
+        sel, num = U.nms_select(tb, ts, tc, thresh, normal=normal, post_max=cap)
+        sel2, num2 = U.nms_batched(tb, ts, tc, thresh) if not normal else (None, None)
+        sel, num = sel.cpu().numpy(), num.cpu().numpy()
+        for s in range(S):
+            c = int(counts[s])
+            order = np.argsort(-scores[s, :c], kind="stable")
+            want, margin = loader.nms(boxes[s, :c][order], thresh, normal=normal)
+            assert num[s] == want.size and np.array_equal(sel[s, :num[s]], order[want]), (s, normal, margin)
+            if c and s % 3 == 0:
+                alone, n_alone = U.nms_select(tb[s:s + 1], ts[s:s + 1], tc[s:s + 1], thresh, normal=normal, post_max=cap)
+                assert int(n_alone[0]) == num[s] and np.array_equal(alone[0, :num[s]].cpu().numpy(), sel[s, :num[s]]), (s, normal)
+            if sel2 is not None:
+                assert int(num2[s]) == num[s] and np.array_equal(sel2[s, :num[s]].cpu().numpy(), sel[s, :num[s]]), s
+
+
 def test_nms_select_limits(cuda_device):
     from openpcdet_amd import _lib
     L = _lib.lib()
