@@ -438,7 +438,7 @@ def main():
         passes = args.profile_passes
         conv_ms = sum(a.elapsed_time(b) for n, l in ev.items() if n.startswith("conv") and not n.startswith("conv_out") for a, b in l) / passes
         conv_launches = sum(1 for n in ev if n.startswith("conv") and not n.startswith("conv_out"))
-        rule_ms = sum(a.elapsed_time(b) for n, l in ev.items() if n in ("site_index", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "index_unset", "index_unset_main") for a, b in l) / passes
+        rule_ms = sum(a.elapsed_time(b) for n, l in ev.items() if n in ("site_index", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tile_schedule", "index_unset", "index_unset_main") for a, b in l) / passes
         dense_ms = sum(a.elapsed_time(b) for a, b in ev.get("dense", [])) / passes
         vox_ms = sum(a.elapsed_time(b) for a, b in stage_ev["voxelize"]) / passes
         nms_ms = sum(a.elapsed_time(b) for a, b in stage_ev["nms"]) / passes

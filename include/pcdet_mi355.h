@@ -357,6 +357,13 @@ int pvx_sparse_conv_fwd(const void* feat_in, int n_in, int cin, const void* prep
 int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype);
 size_t pvx_tilebook_bytes(int n_out);
 int pvx_tilebook_build(const int* nbr, int kvol, int n_out, const int* n_out_dev, int n_in, int rcap, void* book, void* stream);
+/* Tiles dealt to workgroups by cost (no reference counterpart).  The persistent conv kernels walk their tiles round-robin; tiles differ
+ * in cost (dz groups without pairs, groups with far codes) and a launch ends with the workgroup that drew the most.  After a book has
+ * been built (any builder; each one invalidates the previous schedule), pvx_tilebook_schedule writes, into the book's own tail, which
+ * tiles each workgroup of the kernel of (cin, cout, kvol, dtype) takes: same tiles, same sums, a shorter tail.  A shape whose kernel
+ * takes no schedule is left alone (PVX_OK).  The book must have been sized by pvx_tilebook_bytes(n_out) with this n_out.
+ * book == NULL: HOST query, 1 if that kernel walks a schedule for a book of n_out columns, else 0 (nothing is launched). */
+int pvx_tilebook_schedule(void* book, int n_out, const int* n_out_dev, int cin, int cout, int kvol, int dtype, void* stream);
 /* pvx_subm_rulebook for a 3 x 3 x 3 kernel and pvx_tilebook_build of its rulebook (n_in = n) in ONE pass: the 27 entries of a
  * tile's sites are in registers when the rulebook is written, so the book costs its stores only.  Same nbr, same book. */
 int pvx_subm_rulebook_tb(const int* coords, int n, const int* n_dev, int batch, const int* shape_dhw, const void* index,

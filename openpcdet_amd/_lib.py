@@ -128,6 +128,7 @@ SIGNATURES = {
     "pvx_tilebook_rcap": (c_int, [c_int, c_int, c_int, c_int]),
     "pvx_tilebook_bytes": (c_size_t, [c_int]),
     "pvx_tilebook_build": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "pvx_tilebook_schedule": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "pvx_sparse_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "pvx_sparse_conv_wgrad": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(kBlk) void subm_rulebook_tb_kernel(const int* __res
     // where the book says kTbFar -- so only those entries are stored (a few per cent), not 108 B per site
     static_assert(kBlk == kTbTile, "one workgroup = one tile");
     __shared__ int g_lo[3], g_hi[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(book + (size_t)PVX_CDIV(n, kTbTile) * kTbU4)[0] = 0;   // no schedule yet
     const int n_live = live_rows(n, n_dev);
     if ((int)blockIdx.x * kBlk >= n_live) return;              // the whole workgroup: no tile, no book block
     const int o = blockIdx.x * kBlk + threadIdx.x;
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(kBlk) void conv_out_rulebook_kernel(const int* __re
                                                                   int* __restrict__ nbr, int n_in, int rcap,
                                                                   uint4* __restrict__ book, int far_only) {
     __shared__ int g_lo[3], g_hi[3];
+    if (book && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<int*>(book + (size_t)PVX_CDIV(n_out, kTbTile) * kTbU4)[0] = 0;   // no schedule yet
     const int n_live = live_rows(n_out, n_out_dev);
     if ((int)blockIdx.x * kBlk >= n_live) return;              // the whole workgroup
     const int o = blockIdx.x * kBlk + threadIdx.x;

@@ -636,6 +636,15 @@ int num_cus() {
     return (cus + 7) / 8 * 8;
 }
 
+#ifdef PVX_FIN_STAMPS
+// diagnostic build only (tools/probes/fin_spread.py): first and last tick (100 MHz) of every workgroup of the last launch, per kernel family
+__device__ unsigned long long g_fin[2][1024][2];
+#define FIN_BEGIN() const unsigned long long fin_t0_ = __builtin_amdgcn_s_memrealtime()
+#define FIN_END(id) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_fin[id][blockIdx.x][0] = fin_t0_; g_fin[id][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define FIN_BEGIN() do { } while (0)
+#define FIN_END(id) do { } while (0)
+#endif
 #include "sparse_conv_w32.h"
 #include "sparse_conv_slab.h"
 #include "sparse_conv_slab_tb.h"
@@ -902,8 +911,24 @@ extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {
     return w32_shape(cin, cout, kvol, dtype) && slab_shape(cin, cout, kvol, dtype) ? tilebook_rcap_of(cin, cout, kvol, dtype) : 0;
 }
 
+#ifdef PVX_FIN_STAMPS
+extern "C" int pvx_debug_fin(unsigned long long* host_out) {
+    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fin), sizeof(unsigned long long) * 2 * 1024 * 2));
+    return PVX_OK;
+}
+#endif
+
 extern "C" size_t pvx_tilebook_bytes(int n_out) {
-    return n_out <= 0 ? 256 : (size_t)PVX_CDIV(n_out, kTbTile) * kTbU4 * sizeof(uint4);
+    if (n_out <= 0) return 256;
+    const int tiles = PVX_CDIV(n_out, kTbTile);                // the tile blocks, then the schedule area (tilebook_layout.h)
+    return (size_t)tiles * kTbU4 * sizeof(uint4) + (tb_sched_ints(tiles) * sizeof(int) + 15) / 16 * 16;
+}
+
+extern "C" int pvx_tilebook_schedule(void* book, int n_out, const int* n_out_dev, int cin, int cout, int kvol, int dtype, void* stream) {
+    if (n_out < 0) return PVX_ERR_INVALID;
+    const int rc = pvx_st_schedule(book, n_out, n_out_dev, cin, cout, kvol, dtype, stream);
+    if (!book) return rc;                                       // HOST query: 1 = this shape's kernel walks a schedule, 0 = it does not
+    return rc < 0 ? PVX_ERR_HIP : PVX_OK;
 }
 
 extern "C" int pvx_tilebook_build(const int* nbr, int kvol, int n_out, const int* n_out_dev, int n_in, int rcap, void* book,

@@ -19,6 +19,7 @@ __global__ __launch_bounds__(kTbTile) void tilebook_kernel(const int* __restrict
                                                             int n_in, int rcap, uint4* __restrict__ book) {
     __shared__ int g_lo[3], g_hi[3];
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(book + (size_t)PVX_CDIV(n_out, kTbTile) * kTbU4)[0] = 0;   // no schedule yet
     const int n_live = live_rows(n_out, n_out_dev);
     const int tile = blockIdx.x;
     if (tile * kTbTile >= n_live) return;
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_roll_kernel(const E* 
     __shared__ uint4 rlds[RCAP * RS_U4];
     __shared__ float epi[3 * COUT];                            // bias, scale, shift: read from LDS in the epilogue, so that no
                                                                // vector load there makes the tile wait for the windows in flight
+    FIN_BEGIN();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int n_live = live_rows(n_out, n_out_dev);
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_roll_kernel(const E* 
         // block buffer this tile read its codes from) behind every wave's last read of them.
         __syncthreads();
     }
+    FIN_END(1);
 }
 
 // Shapes that take the rolling form, with ITS window rows: all 27 offsets of weights + a 896-row window + the two book blocks fit

@@ -80,7 +80,92 @@ int launch_st(const void* feat, int n_in, const void* w, const int* nbr, const v
     return PVX_OK;
 }
 
+// One wave per XCD deals that XCD's tiles to its W workgroups (tilebook_layout.h, SCHEDULE): round by round, the round's W tiles sorted
+// by cost (descending) meet the workgroups sorted by the cost they hold so far (ascending).  A tile's cost comes from its meta words:
+// c_tile + per live dz group c_phase, or c_far + c_step x (far steps of the group, meta word 7) when the group has far codes (its phase
+// runs the slow path); group 1 counts as live for every tile, as the kernel runs it.  Costs are staged in LDS first (one round trip for
+// the whole eighth, not one per round); ranks by 64 constant-lane broadcasts per key (v_readlane), keys (value << 6 | lane) distinct.
+constexpr int kSchedStage = 8192;                              // tiles of one XCD whose costs fit the LDS stage (2 M sites per XCD)
+template <int WMAX>                                            // W <= WMAX: the rank loops visit the lanes that can hold a tile or a workgroup
+__global__ __launch_bounds__(64) void tile_schedule_kernel(uint4* __restrict__ book, int n_out, const int* __restrict__ n_out_dev, int W,
+                                                           int c_tile, int c_phase, int c_far, int c_step) {
+    __shared__ int s_tile[64], s_cost[64];
+    __shared__ unsigned short s_stage[kSchedStage];
+    const int lane = threadIdx.x, x = blockIdx.x;
+    const int tiles_alloc = (n_out + kTbTile - 1) / kTbTile;
+    int* sched = reinterpret_cast<int*>(book + (size_t)tiles_alloc * kTbU4);
+    const int R = tb_sched_rounds(tiles_alloc);
+    int* counts = sched + kTbSchedHdr;
+    int* lists = counts + 8 * kTbSchedW;
+    const int ntiles = (live_rows(n_out, n_out_dev) + kTbTile - 1) / kTbTile;
+    const int x_b = (int)((long long)ntiles * x / 8), x_e = (int)((long long)ntiles * (x + 1) / 8);
+    auto cost_of = [&](int tile) {
+        const uint2 m = reinterpret_cast<const uint2*>(book + (size_t)tile * kTbU4 + 1)[1];      // meta words 6 (flags) and 7 (far steps)
+        const unsigned flags = m.x | 2u;
+        int cost = c_tile;
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            if ((flags >> g) & 1u) cost += ((flags >> (4 + g)) & 1u) ? c_phase : c_far + c_step * (int)((m.y >> (5 * g)) & 31u);
+        return cost;
+    };
+    const int staged = (x_e - x_b) < kSchedStage ? (x_e - x_b) : kSchedStage;
+    for (int i = lane; i < staged; i += 64) s_stage[i] = (unsigned short)cost_of(x_b + i);
+    __syncthreads();
+    int acc = 0, cnt = 0;
+    for (int base = x_b; base < x_e; base += W) {              // uniform trip count
+        const int tile = base + lane;
+        int cost = -1;                                          // no tile for this lane in this round
+        if (lane < W && tile < x_e) cost = (tile - x_b) < staged ? (int)s_stage[tile - x_b] : cost_of(tile);
+        const unsigned ka = (lane < W ? (unsigned)acc << 6 : 0xffffffc0u) | (unsigned)lane;      // least loaded first
+        const unsigned kc = ((unsigned)(0xffff - cost) << 6) | (unsigned)lane;                   // heaviest first; "no tile" (cost -1) last
+        int ra = 0, rc = 0;
+#pragma unroll
+        for (int j = 0; j < WMAX; j++) {                        // lanes >= W hold the largest keys: they change no rank below W
+            ra += (unsigned)__builtin_amdgcn_readlane((int)ka, j) < ka;
+            rc += (unsigned)__builtin_amdgcn_readlane((int)kc, j) < kc;
+        }
+        if (lane < WMAX) { s_tile[rc] = cost >= 0 ? tile : -1; s_cost[rc] = cost; }
+        __syncthreads();
+        const int mt = lane < WMAX ? s_tile[ra] : -1, mc = lane < WMAX ? s_cost[ra] : 0;
+        __syncthreads();
+        if (lane < W && mt >= 0) {
+            if (cnt < R) lists[(size_t)(x * kTbSchedW + lane) * R + cnt] = mt;
+            cnt++;
+            acc += mc;
+        }
+    }
+    if (lane < W) counts[x * kTbSchedW + lane] = cnt < R ? cnt : R;
+    const bool complete = __ballot(lane < W && cnt > R) == 0ull;
+    if (lane == 0) {
+        sched[4 + x] = complete ? kTbSchedMagic : 0;
+        if (x == 0) { sched[1] = W; sched[2] = R; sched[3] = ntiles; sched[0] = kTbSchedMagic; }
+    }
+}
+
 }  // namespace
+
+// HOST: the schedule of a book for the kernel that will read it (0 = that kernel walks round-robin; nothing is written)
+int pvx_st_schedule(void* book, int n_out, const int* n_out_dev, int cin, int cout, int kvol, int dtype, void* stream) {
+    const int rcap = pvx_st_rcap(cin, cout, kvol, dtype);
+    if (rcap <= 0 || n_out <= 0) return 0;
+    int ns = 0;
+#define X(ci, co, rc, ns_) if (cin == ci && cout == co) ns = ns_;
+    PVX_ST_SHAPES(X)
+#undef X
+    if (ns != 1) return 0;
+    int grid = num_cus8();                                      // as launch_st
+    const int tiles = PVX_CDIV(n_out, 256);
+    if (grid > tiles) grid = (tiles + 7) / 8 * 8;
+    const int W = grid / 8;
+    if (W > kTbSchedW) return 0;
+    if (!book) return 1;                                        // query only
+    // cycles of the 64 -> 64 kernel per tile epilogue / regular phase / phase with far codes / far step, in units of ~250 (tools/st_stamps.py)
+    if (W <= 32)
+        hipLaunchKernelGGL(tile_schedule_kernel<32>, dim3(8), dim3(64), 0, (hipStream_t)stream, (uint4*)book, n_out, n_out_dev, W, 12, 40, 48, 5);
+    else
+        hipLaunchKernelGGL(tile_schedule_kernel<64>, dim3(8), dim3(64), 0, (hipStream_t)stream, (uint4*)book, n_out, n_out_dev, W, 12, 40, 48, 5);
+    return hipGetLastError() == hipSuccess ? 1 : -1;
+}
 
 #ifdef PVX_ST_STAMPS
 extern "C" int pvx_debug_st_stamps(unsigned long long* host_out, int n_words) {

@@ -59,24 +59,36 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_ws_kernel(const E* __
     const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, W = (int)(gridDim.x >> 3);
     const int x_b = (int)((long long)ntiles * xcd / 8), x_e = (int)((long long)ntiles * (xcd + 1) / 8);
     const int r_full = (x_e - x_b) / (W * NS), rem_b = x_b + r_full * W * NS;
-    const int n_rounds = r_full + (rem_b + wg < x_e ? (x_e - rem_b - wg + W - 1) / W : 0);
+    // a schedule made for this grid and this live count (tilebook_layout.h): the workgroup walks ITS list of the XCD's tiles, dealt by
+    // cost, instead of every W-th tile.  One tile per round (NS = 1).
+    typedef const int __attribute__((address_space(4)))* SchedPtr;
+    const SchedPtr sched = (SchedPtr)(book + (size_t)((n_out + TM - 1) / TM) * kTbU4);
+    const bool sched_on = NS == 1 && W <= kTbSchedW && sched[0] == kTbSchedMagic && sched[1] == W && sched[3] == ntiles &&
+                          sched[4 + xcd] == kTbSchedMagic;
+    const SchedPtr my_list = sched + kTbSchedHdr + 8 * kTbSchedW + (size_t)(xcd * kTbSchedW + wg) * (sched_on ? sched[2] : 0);
+    const int n_rounds = sched_on ? sched[kTbSchedHdr + xcd * kTbSchedW + wg]
+                                  : r_full + (rem_b + wg < x_e ? (x_e - rem_b - wg + W - 1) / W : 0);
     if (n_rounds == 0) return;
-    auto round_t0 = [&](int r) __attribute__((always_inline)) { return r < r_full ? x_b + (r * W + wg) * NS : rem_b + (r - r_full) * W + wg; };
-    auto round_n = [&](int r) __attribute__((always_inline)) { return r < r_full ? NS : (r < n_rounds ? 1 : 0); };
+    auto round_t0 = [&](int r) __attribute__((always_inline)) {
+        if (sched_on) return r < n_rounds ? my_list[r] : x_b;
+        return r < r_full ? x_b + (r * W + wg) * NS : rem_b + (r - r_full) * W + wg;
+    };
+    auto round_n = [&](int r) __attribute__((always_inline)) { return (!sched_on && r < r_full) ? NS : (r < n_rounds ? 1 : 0); };
+    int tq[4] = { round_t0(0), round_t0(1), round_t0(2), round_t0(3) };      // first tiles of rounds r .. r + 3, kept in registers
 
     // A tile's meta words { lo0, cnt0, lo1, cnt1, lo2, cnt2, flags, - } by scalar loads; slots without a tile read as "no pairs".
     // Group 1 is made live for every tile (it holds the centre offset, so for a submanifold rulebook it is live anyway; for any
     // other rulebook an empty group costs a phase of zero MFMAs): every round then has a phase, and the next phase is always found
     // within this round or the next one.
     const u32x8 kNoTile = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-    auto meta = [&](int r, int s) __attribute__((always_inline)) {
+    auto meta = [&](int r, int t0, int s) __attribute__((always_inline)) {
         u32x8 m = kNoTile;
-        if (s < round_n(r)) { m = *(MetaPtr)(book + (size_t)(round_t0(r) + s) * kTbU4); m[6] |= 2u; }
+        if (s < round_n(r)) { m = *(MetaPtr)(book + (size_t)(t0 + s) * kTbU4); m[6] |= 2u; }
         return m;
     };
     u32x8 cur[NS], nxt[NS], aft[NS];                           // rounds r, r + 1, r + 2: a scalar load shares lgkmcnt with the LDS reads, so it
 #pragma unroll                                                 // is issued long before anything can wait for it
-    for (int s = 0; s < NS; s++) { cur[s] = meta(0, s); nxt[s] = meta(1, s); aft[s] = meta(2, s); }
+    for (int s = 0; s < NS; s++) { cur[s] = meta(0, tq[0], s); nxt[s] = meta(1, tq[1], s); aft[s] = meta(2, tq[2], s); }
     auto m_cnt = [](const u32x8& m, int g) __attribute__((always_inline)) { return (int)(g == 0 ? m[1] : (g == 1 ? m[3] : m[5])); };
     // the first live phase behind phase `from` of round r, in execution order (dz-major within the round, then the next round);
     // everything here is uniform, the loops unroll to select chains
@@ -86,21 +98,22 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_ws_kernel(const E* __
         for (int p = 0; p < NP; p++) {
             const int g = p / NS, s = p % NS;
             if (p > from && !found && ((cur[s][6] >> g) & 1u)) {
-                found = true; ntile = round_t0(r) + s; ng = g; nlo = (int)cur[s][2 * g]; ncnt = (int)cur[s][2 * g + 1];
+                found = true; ntile = tq[0] + s; ng = g; nlo = (int)cur[s][2 * g]; ncnt = (int)cur[s][2 * g + 1];
             }
         }
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int g = p / NS, s = p % NS;
             if (!found && ((nxt[s][6] >> g) & 1u)) {
-                found = true; ntile = round_t0(r + 1) + s; ng = g; nlo = (int)nxt[s][2 * g]; ncnt = (int)nxt[s][2 * g + 1];
+                found = true; ntile = tq[1] + s; ng = g; nlo = (int)nxt[s][2 * g]; ncnt = (int)nxt[s][2 * g + 1];
             }
         }
         return found;
     };
     auto rotate = [&](int r) __attribute__((always_inline)) {
+        tq[0] = tq[1]; tq[1] = tq[2]; tq[2] = tq[3]; tq[3] = round_t0(r + 4);
 #pragma unroll
-        for (int s = 0; s < NS; s++) { cur[s] = nxt[s]; nxt[s] = aft[s]; aft[s] = meta(r + 3, s); }
+        for (int s = 0; s < NS; s++) { cur[s] = nxt[s]; nxt[s] = aft[s]; aft[s] = meta(r + 3, tq[2], s); }
     };
 #ifdef PVX_ST_STAMPS
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_ws_kernel(const E* __
                 const int i = q * NH + h;
                 wt[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (req_w && i < W_U4) ? (unsigned)(ng * W_U4 + i) * 16u : kOob, 0, 0);
             }
-            const int nt_ok = found ? ntile : round_t0(0);       // always a valid block of the book
+            const int nt_ok = found ? ntile : x_b;               // always a valid block of the book
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 const int i = q * NH + h;
@@ -266,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_ws_kernel(const E* __
     bool epi_pending = false;                                  // a finished super-tile's sums wait in acc for the next phase's LDS-write gap
     int epi_t0 = 0, epi_n = 0;
     for (int r = 0; r < n_rounds; r++) {
-        const int t0 = round_t0(r);
+        const int t0 = tq[0];
         bool fresh = true;                                     // no phase of this super-tile has run yet
 #pragma unroll 1
         for (int g = 0; g < 3; g++) {

@@ -210,6 +210,7 @@ class HotPathEngine:
         # a submanifold rulebook all of whose layers read it through ONE tile book is stored as that book + its far entries only
         # (pvx_subm_book / pvx_sparse_conv_fwd_book); PVX_ENGINE_FAR_ONLY=0: full int32 rulebooks (A/B switch)
         self.far_only = os.environ.get("PVX_ENGINE_FAR_ONLY", "1") != "0"
+        self.schedule = os.environ.get("PVX_ENGINE_SCHEDULE", "1") != "0"
         self.conv_records = [] # per conv launch: dict(name, cin, cout, kvol, nbr, level_out) for flop accounting
         keep = []              # keeps ctypes arrays / tensors alive
         self._keep = keep
@@ -261,6 +262,11 @@ class HotPathEngine:
                     else:
                         ab = (_lib.ptr(nbr), kvol, level_out.cap, _lib.ptr(level_out.n_dev), level_in.cap, rcap, _lib.ptr(book))
                         self.ops.append(("tilebook", lambda st, a=ab: _lib.check(L.pvx_tilebook_build(*a, st), "pvx_tilebook_build")))
+                    # tiles dealt to the kernel's workgroups by cost, for the kernels that walk such a schedule (after the book's builder,
+                    # which runs earlier in self.ops whichever branch built it)
+                    if self.schedule and L.pvx_tilebook_schedule(None, level_out.cap, None, cin, cout, kvol, self.code, None) == 1:
+                        asd = (_lib.ptr(book), level_out.cap, _lib.ptr(level_out.n_dev), cin, cout, kvol, self.code)
+                        self.ops.append(("tile_schedule", lambda st, a=asd: _lib.check(L.pvx_tilebook_schedule(*a, st), "pvx_tilebook_schedule")))
             args = (_lib.ptr(feat_in), level_in.cap, cin, _lib.ptr(pw), _lib.ptr(bias), _lib.ptr(nbr), kvol, level_out.cap,
                     _lib.ptr(level_out.n_dev), cout, self.code, _lib.ptr(scale), _lib.ptr(shift),
                     _lib.ptr(residual_buf) if residual_buf is not None else None, 1 if spec.relu else 0, _lib.ptr(out),
@@ -433,7 +439,7 @@ class HotPathEngine:
                 hook(name, lambda: fn(st))
         self._end_ops()
 
-    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook", "index_unset")
+    _GEOMETRY = ("site_index", "sort_sites", "subm_rulebook", "conv_out_index", "conv_out_rulebook", "tilebook", "tile_schedule", "index_unset")
 
     def voxelize_ahead(self, stream, load=None, after=None):
         """Voxelize the NEXT batch of this plan on `stream` while another plan's rulebooks are being built: waits for this
@@ -575,7 +581,8 @@ class HotPathEngine:
             lvl = r["level_out"]
             n = min(int(lvl.n_dev.item()), lvl.cap)
             if r["far_only"]:    # the int32 rulebook holds the far entries only: count the book's codes (0xFFFF = no neighbour)
-                codes = r["book"].view(torch.int16).view(-1, 8 * self.L.pvx_tilebook_bytes(256) // 16)[:, 16:].reshape(-1, 27, 256)
+                tiles = -(-lvl.cap // 256)                           # the tile blocks come first, the schedule area follows them
+                codes = r["book"][:tiles * 866 * 16].view(torch.int16).view(-1, 866 * 8)[:, 16:].reshape(-1, 27, 256)
                 live = (torch.arange(codes.shape[0] * 256, device=codes.device) < n).view(-1, 1, 256)
                 pairs = int(((codes != -1) & live).sum().item())
             else:

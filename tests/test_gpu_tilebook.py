@@ -16,6 +16,11 @@ pytestmark = pytest.mark.gpu
 SHAPES = [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64)]
 
 
+def tile_blocks(book, tiles):
+    """the first `tiles` 866 x 16-byte tile blocks of a book buffer as uint32 rows (the schedule area lies behind the blocks)"""
+    return book.cpu().numpy()[:tiles * 866 * 16].view(np.uint32).reshape(tiles, 866 * 4)
+
+
 def rel_l2(got, want):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
@@ -51,6 +56,9 @@ def book_numpy(nbr, n_live, n_in, rcap):
                 local = blk - wlo
                 code = np.where(blk < 0, 0xFFFF, np.where((local >= 0) & (local < cnt), local, 0xFFFE))
                 ent[t, g * 9:(g + 1) * 9, :s1 - s0] = code
+                # word 7: far steps of the group = max over the tile's four 64-site waves of its (offset, 32-site block) pairs with a far code
+                farb = (ent[t, g * 9:(g + 1) * 9] == 0xFFFE).reshape(9, 4, 2, 32).any(-1)        # [offset, wave, block]
+                meta[t, 7] |= int(farb.sum((0, 2)).max()) << (5 * g)
     return meta, ent
 
 
@@ -93,8 +101,8 @@ def test_tilebook_conv_bit_identical(cuda_device, cin, cout, sort):
         _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, cap, _lib.ptr(n_live), cap, rcap, _lib.ptr(book), _lib.stream()), "build")
         # the book itself
         meta, ent = book_numpy(nbr, n, cap, rcap)
-        raw = book.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:meta.shape[0]]
-        assert np.array_equal(raw[:, :7], meta[:, :7])
+        raw = tile_blocks(book, meta.shape[0])
+        assert np.array_equal(raw[:, :8], meta[:, :8])
         got_ent = raw[:, 8:].copy().view(np.uint16).reshape(-1, 27, 256)
         assert np.array_equal(got_ent, ent.astype(np.uint16))
         far = (ent == 0xFFFE).mean()
@@ -114,6 +122,77 @@ def test_tilebook_conv_bit_identical(cuda_device, cin, cout, sort):
         # a book built for another window size is refused in favour of the plain kernels (still the same result)
         got2, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, book=book, rcap=rcap + 1, residual=res)
         assert torch.equal(got2[:n], want[:n])
+
+
+@pytest.mark.parametrize("n_sites,sort", [(150000, True), (150000, False), (9000, True)])
+def test_tile_schedule(cuda_device, n_sites, sort):
+    """pvx_tilebook_schedule: every live tile of an XCD's eighth lands in exactly one workgroup's list, in ascending order, the lists
+    are balanced by the cost model's own measure, a rebuilt book invalidates the schedule, and the conv that walks the schedule gives
+    the bits of the plain kernels (with a live count below the capacity, and a second conv after the live count changed)."""
+    L = _lib.lib()
+    dev = cuda_device
+    shape, batch = [12, 200, 220], 2
+    coords = sites(61, batch, shape, n_sites, sort)
+    n = len(coords)
+    cap = n + 700
+    nbr = np.full((27, cap), -1, np.int32)
+    nbr[:, :n] = loader.subm_rulebook(coords, shape, (3, 3, 3))
+    nbr_t = torch.from_numpy(nbr).to(dev)
+    r = np.random.default_rng(8)
+    tested = 0
+    for cin, cout in SHAPES + [(128, 128)]:
+        if L.pvx_tilebook_schedule(None, cap, None, cin, cout, 27, 2, None) != 1:
+            continue
+        tested += 1
+        rcap = L.pvx_tilebook_rcap(cin, cout, 27, 2)
+        feat = torch.from_numpy(r.normal(size=(cap, cin)).astype(np.float32)).to(dev).bfloat16()
+        w = torch.from_numpy((r.normal(size=(cout, 27, cin)) / np.sqrt(27 * cin)).astype(np.float32)).to(dev).bfloat16()
+        res = torch.from_numpy(r.normal(size=(cap, cout)).astype(np.float32)).to(dev).bfloat16()
+        book = torch.full((L.pvx_tilebook_bytes(cap),), 0xA5, dtype=torch.uint8, device=dev)       # garbage behind the blocks
+        tiles_alloc = (cap + 255) // 256
+        for live in (n, n // 3):
+            n_live = torch.tensor([live], dtype=torch.int32, device=dev)
+            _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, cap, _lib.ptr(n_live), cap, rcap, _lib.ptr(book), _lib.stream()), "build")
+            sched = book[tiles_alloc * 866 * 16:].view(torch.int32)
+            assert int(sched[0]) == 0                       # the builder invalidates whatever was there
+            want, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, 2, residual=res)
+            unsched, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, 2, book=book, rcap=rcap, residual=res)
+            assert torch.equal(unsched, want)
+            _lib.check(L.pvx_tilebook_schedule(_lib.ptr(book), cap, _lib.ptr(n_live), cin, cout, 27, 2, _lib.stream()), "schedule")
+            hdr = sched[:16].cpu().numpy()
+            ntiles = (live + 255) // 256
+            W, R = int(hdr[1]), int(hdr[2])
+            assert hdr[0] == 0x5c4ed01e and hdr[3] == ntiles and all(hdr[4 + x] == 0x5c4ed01e for x in range(8)) and 1 <= W <= 64
+            counts = sched[16:16 + 512].cpu().numpy().reshape(8, 64)
+            lists = sched[16 + 512:16 + 512 + 512 * R].cpu().numpy().reshape(8, 64, R)
+            blocks = tile_blocks(book, ntiles)
+            meta, steps = blocks[:, 6] | 2, blocks[:, 7]          # flags (group 1 always runs), far steps per group (5 bits each)
+            cost = 12 + sum(np.where((meta >> g) & 1, np.where((meta >> (4 + g)) & 1, 40, 48 + 5 * ((steps >> (5 * g)) & 31)), 0)
+                            for g in range(3)).astype(np.int64)
+            for x in range(8):
+                lo, hi = ntiles * x // 8, ntiles * (x + 1) // 8
+                got = []
+                loads = []
+                for wq in range(W):
+                    c = int(counts[x, wq])
+                    mine = lists[x, wq, :c]
+                    assert np.all(np.diff(mine) > 0)        # ascending: neighbouring tiles stay neighbours in time
+                    got.extend(mine.tolist())
+                    loads.append(int(cost[mine].sum()))
+                assert sorted(got) == list(range(lo, hi)), x
+                if hi - lo >= 2 * W:
+                    assert max(loads) - min(loads) <= 2 * int(cost.max()), (x, loads)      # within two of the heaviest tiles of each other
+            got, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, 2, book=book, rcap=rcap, residual=res)
+            assert torch.equal(got, want), (cin, cout, live)
+        # a schedule made for another live count is ignored (the kernel compares it with its own)
+        n_other = torch.tensor([n // 2], dtype=torch.int32, device=dev)
+        _lib.check(L.pvx_tilebook_build(_lib.ptr(nbr_t), 27, cap, _lib.ptr(n_other), cap, rcap, _lib.ptr(book), _lib.stream()), "build")
+        sched[0] = 0x5c4ed01e                               # pretend the old schedule (made for n // 3 rows) were still valid
+        want, _ = run_conv(dev, feat, w, nbr_t, n_other, cin, cout, 2, residual=res)
+        got, _ = run_conv(dev, feat, w, nbr_t, n_other, cin, cout, 2, book=book, rcap=rcap, residual=res)
+        assert torch.equal(got, want)
+    assert tested > 0
+    assert L.pvx_tilebook_schedule(None, cap, None, 16, 16, 27, 2, None) == 0 and L.pvx_tilebook_schedule(None, -1, None, 64, 64, 27, 2, None) == -1
 
 
 def test_tilebook_strided_rulebook_and_empty(cuda_device):
@@ -206,8 +285,8 @@ def test_fused_subm_rulebook_and_book(cuda_device, sort):
                                           _lib.ptr(nbr_b), rcap, _lib.ptr(book_b), _lib.stream()), "fused")
         assert torch.equal(nbr_a, nbr_b)                      # rows past the live count untouched by both
         tiles = (n + 255) // 256
-        a = book_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
-        b = book_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+        a = tile_blocks(book_a, tiles)
+        b = tile_blocks(book_b, tiles)
         assert np.array_equal(a[:, :7], b[:, :7]) and np.array_equal(a[:, 8:], b[:, 8:])
     assert L.pvx_subm_rulebook_tb(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx), _lib.ptr(perm), d3,
                                   _lib.ptr(nbr_b), 0, _lib.ptr(book_b), None) == -1
@@ -295,7 +374,7 @@ def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
         obook_a = torch.zeros(L.pvx_tilebook_bytes(ocap), dtype=torch.uint8, device=dev)
         _lib.check(L.pvx_tilebook_build(_lib.ptr(onbr), 27, ocap, _lib.ptr(no_b), cap, rcap_o, _lib.ptr(obook_a), _lib.stream()), "build")
         otiles = (n_out + 255) // 256
-        want_book = obook_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:otiles]
+        want_book = tile_blocks(obook_a, otiles)
         ocodes = np.ascontiguousarray(want_book[:, 8:]).view(np.uint16).reshape(otiles, 27, 256).transpose(1, 0, 2).reshape(27, otiles * 256)[:, :n_out]
         for far_only in (0, 1):
             obook_b = torch.zeros(L.pvx_tilebook_bytes(ocap), dtype=torch.uint8, device=dev)
@@ -303,7 +382,7 @@ def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
             ocoords_b = torch.zeros((ocap, 4), dtype=torch.int32, device=dev)
             _lib.check(L.pvx_conv_out_book(_lib.ptr(oidx_b), ocap, _lib.ptr(no_b), batch, s3, k3, st3, p3, d3, _lib.ptr(idx_a), _lib.ptr(perm_a),
                                            _lib.ptr(ocoords_b), _lib.ptr(onbr_b), cap, rcap_o, _lib.ptr(obook_b), far_only, _lib.stream()), "out book")
-            got_book = obook_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:otiles]
+            got_book = tile_blocks(obook_b, otiles)
             assert np.array_equal(want_book[:, :7], got_book[:, :7]) and np.array_equal(want_book[:, 8:], got_book[:, 8:])
             assert torch.equal(ocoords_b, ocoords)
             if far_only:
@@ -329,8 +408,8 @@ def test_clean_index_protocol_and_far_only_book(cuda_device, sort):
     _lib.check(L.pvx_subm_book(_lib.ptr(coords_t), cap, _lib.ptr(n_dev), batch, s3, _lib.ptr(idx_a), _lib.ptr(perm_a), d3,
                                _lib.ptr(nbr_far), rcap, _lib.ptr(book_b), _lib.stream()), "book")
     tiles = (n + 255) // 256
-    a = book_a.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
-    b = book_b.cpu().numpy().view(np.uint32).reshape(-1, 866 * 4)[:tiles]
+    a = tile_blocks(book_a, tiles)
+    b = tile_blocks(book_b, tiles)
     assert np.array_equal(a[:, :7], b[:, :7]) and np.array_equal(a[:, 8:], b[:, 8:])
     codes = np.ascontiguousarray(a[:, 8:]).view(np.uint16).reshape(tiles, 27, 256).transpose(1, 0, 2).reshape(27, tiles * 256)[:, :n]
     far = codes == 0xFFFE

@@ -55,6 +55,13 @@ def main():
                         w = a[:, 4:, q]
                         print("   %-26s %9.0f cyc per wave   (min wg %9.0f  max wg %9.0f)" % (SEG_WS[q], w.mean(), w.mean(axis=1).min(), w.mean(axis=1).max()))
                     print("   total M %.0f   L %.0f" % (a[:, :4, :4].sum(axis=2).mean(), a[:, 4:, 4:].sum(axis=2).mean()))
+                    # per-workgroup run time (wave 0, first stamp to last): the launch ends with the slowest one
+                    tot = a[:, 0, :4].sum(axis=1) + a[:, 0, 6] + a[:, 0, 7]
+                    tot = tot[tot > 0]
+                    print("   per-workgroup total (wave 0): min %.0f  p10 %.0f  mean %.0f  p90 %.0f  max %.0f   -> idle at the tail %.1f %% of the launch"
+                          % (tot.min(), np.percentile(tot, 10), tot.mean(), np.percentile(tot, 90), tot.max(), 100 * (1 - tot.mean() / tot.max())))
+                    xc = tot[:256].reshape(-1, 8)      # workgroup b runs on XCD b % 8
+                    print("   per-XCD mean: " + " ".join("%.0f" % v for v in xc.mean(axis=0)))
                     if "128x128" in name:      # three roles: weight waves 4-5 (4 barrier waits, 5 write + request, 6 chunk barrier waits, 7 tails), window waves 6-7
                         for nm, sl in (("weight waves", slice(4, 6)), ("window waves", slice(6, 8))):
                             print("   %s: " % nm + "  ".join("seg%d %.0f" % (q, a[:, sl, q].mean()) for q in range(4, 8)))
