@@ -365,6 +365,31 @@ def main():
         wd.tick("warm-up enqueued")
         elapsed = pdist.timed_steps(timed_step, args.steps, device=dev, first=args.warmup)
         wd.tick("timed region done")
+        if os.environ.get("PVX_FIN_DUMP"):      # diagnostic build (tools/build_fin.sh): how evenly the rolling / streaming conv launches INSIDE the
+            import ctypes                       # overlapped schedule start and finish their workgroups (ring of the last 64 launches per family)
+            import numpy as np
+            # keep the pipeline full behind the launches that are looked at: a few more steps, then everything but the last ones counts
+            for i in range(args.warmup + args.steps, args.warmup + args.steps + 4):
+                step(i)
+            torch.cuda.synchronize()
+            from openpcdet_amd import _lib as _l
+            buf = (ctypes.c_ulonglong * (2 * 64 * 1024 * 2))()
+            ctr = (ctypes.c_uint * 2)()
+            assert ctypes.CDLL(_l.LIB_PATH).pvx_debug_fin(buf, ctr) == 0
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(2, 64, 1024, 2).astype(np.float64)
+            for nm, k in (("streaming 128->128 / 64->128", 0), ("rolling 32->32", 1)):
+                rows = []
+                for slot in range(64):
+                    w = a[k, slot][a[k, slot][:, 1] > 0]
+                    if len(w) < 8:
+                        continue
+                    t0 = w[:, 0].min()
+                    st, en = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0
+                    rows.append((t0, np.percentile(st, 50), np.percentile(st, 90), st.max(), en.min(), en.mean(), en.max(), (en - st).mean()))
+                rows.sort()
+                rows = np.array(rows[:-10])                  # the last launches ran with nothing behind them
+                print("[fin] %-30s %3d launches | start p50 %.1f p90 %.1f max %.1f us | finish min %.0f mean %.0f max %.0f us | own run time %.0f us | idle at the tail %.1f %%"
+                      % ((nm, len(rows)) + tuple(rows[:, 1:].mean(axis=0)) + (100 * (1 - rows[:, 5].mean() / rows[:, 6].mean()),)), file=sys.stderr, flush=True)
         # the conv launches' durations INSIDE this schedule (beside the geometry / NMS streams): six more steps with an event pair
         # around every conv launch; outside the timed region
         ov_events = []

@@ -637,12 +637,17 @@ int num_cus() {
 }
 
 #ifdef PVX_FIN_STAMPS
-// diagnostic build only (tools/probes/fin_spread.py): first and last tick (100 MHz) of every workgroup of the last launch, per kernel family
-__device__ unsigned long long g_fin[2][1024][2];
-#define FIN_BEGIN() const unsigned long long fin_t0_ = __builtin_amdgcn_s_memrealtime()
-#define FIN_END(id) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_fin[id][blockIdx.x][0] = fin_t0_; g_fin[id][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+// diagnostic build only (tools/build_fin.sh, tools/probes/fin_spread.py, bench.py PVX_FIN_DUMP): first and last tick (100 MHz) of every
+// workgroup of the last 64 launches per kernel family (0 streaming, 1 rolling).  Launches of a family are serialised on their stream, so
+// ticket / gridDim.x is the launch's number.
+__device__ unsigned long long g_fin[2][64][1024][2];
+__device__ unsigned g_fin_ctr[2];
+#define FIN_BEGIN(id) const unsigned long long fin_t0_ = __builtin_amdgcn_s_memrealtime(); \
+                      unsigned fin_tk_ = 0; if (threadIdx.x == 0) fin_tk_ = atomicAdd(&g_fin_ctr[id], 1u)
+#define FIN_END(id) do { if (threadIdx.x == 0) { unsigned long long* e_ = g_fin[id][(fin_tk_ / gridDim.x) & 63][(fin_tk_ % gridDim.x) & 1023]; \
+                                                 e_[0] = fin_t0_; e_[1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
-#define FIN_BEGIN() do { } while (0)
+#define FIN_BEGIN(id) do { } while (0)
 #define FIN_END(id) do { } while (0)
 #endif
 #include "sparse_conv_w32.h"
@@ -912,8 +917,9 @@ extern "C" int pvx_tilebook_rcap(int cin, int cout, int kvol, int dtype) {
 }
 
 #ifdef PVX_FIN_STAMPS
-extern "C" int pvx_debug_fin(unsigned long long* host_out) {
-    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fin), sizeof(unsigned long long) * 2 * 1024 * 2));
+extern "C" int pvx_debug_fin(unsigned long long* host_out, unsigned* launches_out) {       // [2][64][1024][2] ticks, [2] tickets
+    PVX_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fin), sizeof(unsigned long long) * 2 * 64 * 1024 * 2));
+    PVX_CHECK_HIP(hipMemcpyFromSymbol(launches_out, HIP_SYMBOL(g_fin_ctr), sizeof(unsigned) * 2));
     return PVX_OK;
 }
 #endif

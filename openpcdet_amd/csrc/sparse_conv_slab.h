@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
     __shared__ u32x4 rlds[RCAP * RS_U4];
     __shared__ int g_lo[3], g_hi[3];
     const u32x4* __restrict__ wfrag = reinterpret_cast<const u32x4*>(wfrag_);
-    FIN_BEGIN();
+    FIN_BEGIN(0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool wlane = TL::GROUP_U4 >= NT || tid < TL::GROUP_U4;   // only matters when an offset has fewer than NT 16-byte pieces

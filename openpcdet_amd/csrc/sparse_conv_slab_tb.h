@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void sparse_conv_slab_roll_kernel(const E* 
     __shared__ uint4 rlds[RCAP * RS_U4];
     __shared__ float epi[3 * COUT];                            // bias, scale, shift: read from LDS in the epilogue, so that no
                                                                // vector load there makes the tile wait for the windows in flight
-    FIN_BEGIN();
+    FIN_BEGIN(1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const int n_live = live_rows(n_out, n_out_dev);
