@@ -529,6 +529,15 @@ int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
     int grid = num_cus() * (STREAM >= 2 ? 2 : 1);      // workgroups per CU that LDS (and the launch bounds) admit
     const int tiles = PVX_CDIV(n_out, 256);
+    if constexpr (STREAM == 1 || STREAM == 2) {
+        // The streaming kernel keeps nothing from one tile to the next, so it gains nothing from being persistent -- and a launch of
+        // MORE workgroups than the chip holds lets the dispatcher deal the tiles as CUs come free (a workgroup that started late behind
+        // another stream's kernel, or drew expensive tiles, takes fewer): PVX_STREAM_WGS workgroups per resident slot, 0 = one per tile.
+        // Two measured best (128 -> 128 launches -1.5 %, bench +0.3-0.7 %; 3, 4 and one per tile lose to the per-workgroup start-up:
+        // profiles/r03_tile_schedule.txt).
+        static const int mult = [] { const char* e = getenv("PVX_STREAM_WGS"); return e ? atoi(e) : 2; }();
+        grid = mult <= 0 ? (tiles + 7) / 8 * 8 : grid * mult;
+    }
     if (grid > tiles) grid = (tiles + 7) / 8 * 8;
     if constexpr (STREAM == 1 || STREAM == 2) {
         hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP, (STREAM == 2 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
