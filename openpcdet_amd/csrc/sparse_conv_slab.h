@@ -13,6 +13,7 @@
 // Correctness does not depend on the ordering: a group whose [min, max] span exceeds the LDS capacity (unsorted input
 // such as first-come voxel rows, or a tile that straddles two z-planes) falls back to range-checked buffer gathers.
 #pragma once
+#include "tilebook_layout.h"
 
 template <typename E, int CIN, int COUT, int RCAP, int WGS, bool PF>
 __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
@@ -253,10 +254,13 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_kernel(const E*
 template <typename E, int CIN, int COUT, int RCAP, int WGS>
 __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(const E* __restrict__ feat, int n_in, unsigned feat_bytes,
                                                                       const uint4* __restrict__ wfrag_, const int* __restrict__ nbr,
+                                                                      const uint4* __restrict__ book,
                                                                       int n_out, const int* __restrict__ n_out_dev,
                                                                       const float* __restrict__ bias, const float* __restrict__ scale,
                                                                       const float* __restrict__ shift, const E* __restrict__ residual,
                                                                       int relu, E* __restrict__ out) {
+    // book (may be NULL): the rulebook's tile book built for THIS window size (tilebook_layout.h).  Only its meta words are read: the
+    // row window of each dz group, which otherwise costs a first pass over the tile's 27 KiB of rulebook and two barriers per tile.
     typedef Tiling32<CIN, COUT> TL;
     constexpr int T = TL::T, S = TL::S, NT = 512, TM = 256, K = 27, GK = 9;
     constexpr int ROW_U4 = CIN * (int)sizeof(E) / 16, RS_U4 = ROW_U4 + 1;
@@ -284,6 +288,14 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
 
     for (int tile = tile_begin + wg_in_xcd; tile < tile_end; tile += wgs_per_xcd) {
         const int tile0 = tile * TM;
+        int w_lo[3], w_cnt[3];                         // the window of each dz group (rows lo .. lo + cnt), cnt 0 = the group has no pair
+        bool w_all[3];                                 // every neighbour of the group lies inside it
+        if (book) {
+            const uint4 m0 = book[(size_t)tile * kTbU4], m1 = book[(size_t)tile * kTbU4 + 1];
+            w_lo[0] = (int)m0.x; w_cnt[0] = (int)m0.y; w_lo[1] = (int)m0.z; w_cnt[1] = (int)m0.w; w_lo[2] = (int)m1.x; w_cnt[2] = (int)m1.y;
+#pragma unroll
+            for (int gg = 0; gg < 3; gg++) { if (!((m1.z >> gg) & 1u)) w_cnt[gg] = 0; w_all[gg] = (m1.z >> (4 + gg)) & 1u; }
+        } else {
         __syncthreads();
         if (tid < 3) { g_lo[tid] = 0x7fffffff; g_hi[tid] = -1; }
         __syncthreads();
@@ -319,6 +331,17 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
             }
         }
         __syncthreads();
+#pragma unroll
+        for (int gg = 0; gg < 3; gg++) {
+            w_lo[gg] = 0; w_cnt[gg] = 0; w_all[gg] = true;
+            if (g_hi[gg] >= 0) {
+                const int span = g_hi[gg] - g_lo[gg] + 1;
+                w_cnt[gg] = span <= RCAP ? span : RCAP;
+                w_lo[gg] = span <= RCAP ? g_lo[gg] : g_lo[gg] + (span - RCAP) / 2;
+                w_all[gg] = span <= RCAP;
+            }
+        }
+        }
 
         f32x16 acc[T];
 #pragma unroll
@@ -329,14 +352,13 @@ __global__ __launch_bounds__(512, 2 * WGS) void sparse_conv_slab_stream_kernel(c
 
 #pragma unroll 1
         for (int g = 0; g < 3; g++) {
-            if (g_hi[g] < 0) continue;
-            const int span = g_hi[g] - g_lo[g] + 1;
-            const int cnt = span <= RCAP ? span : RCAP;
-            const int lo = span <= RCAP ? g_lo[g] : g_lo[g] + (span - RCAP) / 2;
+            const int cnt = g == 0 ? w_cnt[0] : (g == 1 ? w_cnt[1] : w_cnt[2]);
+            if (cnt == 0) continue;
+            const int lo = g == 0 ? w_lo[0] : (g == 1 ? w_lo[1] : w_lo[2]);
 #ifdef PVX_SLAB_ABL_NOFALLBACK
             const bool all_in = true;
 #else
-            const bool all_in = span <= RCAP;
+            const bool all_in = g == 0 ? w_all[0] : (g == 1 ? w_all[1] : w_all[2]);
 #endif
             __syncthreads();                               // the previous group is done with wlds / rlds / nlds
             {
@@ -524,7 +546,7 @@ inline bool slab_shape(int cin, int cout, int K, int dtype) {
 
 template <typename E, int CIN, int COUT, int RCAP, int STREAM>
 int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n_out, const int* n_out_dev, const float* bias,
-                const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st) {
+                const float* scale, const float* shift, const void* residual, int relu, void* out, hipStream_t st, const void* book = nullptr) {
     const unsigned long long feat_bytes = (unsigned long long)n_in * CIN * sizeof(E);
     if (feat_bytes >= 0x80000000ull) return PVX_ERR_RANGE;
     int grid = num_cus() * (STREAM >= 2 ? 2 : 1);      // workgroups per CU that LDS (and the launch bounds) admit
@@ -541,7 +563,7 @@ int launch_slab(const void* feat, int n_in, const void* w, const int* nbr, int n
     if (grid > tiles) grid = (tiles + 7) / 8 * 8;
     if constexpr (STREAM == 1 || STREAM == 2) {
         hipLaunchKernelGGL((sparse_conv_slab_stream_kernel<E, CIN, COUT, RCAP, (STREAM == 2 ? 2 : 1)>), dim3(grid), dim3(512), 0, st, (const E*)feat, n_in,
-                           (unsigned)feat_bytes, (const uint4*)w, nbr, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
+                           (unsigned)feat_bytes, (const uint4*)w, nbr, (const uint4*)book, n_out, n_out_dev, bias, scale, shift, (const E*)residual,
                            relu, (E*)out);
     } else {
         bool done = false;

@@ -502,7 +502,7 @@ inline int tilebook_rcap_of(int cin, int cout, int K, int dtype) {
     if (on < 0) { const char* e = getenv("PVX_CONV_TILEBOOK"); on = e ? atoi(e) : 1; }   // PVX_CONV_TILEBOOK=0: A/B switch
     if (!on) return 0;
     if (roll_shape(cin, cout)) return kRollRcap;
-#define X(ci, co, rc, st) if (cin == ci && cout == co && (st == 0 || st == 3)) return rc;
+#define X(ci, co, rc, st) if (cin == ci && cout == co) return rc;       // st 1 / 2 (streaming kernels): the book's window spans only
     PVX_SLAB_SHAPES(X)
 #undef X
     return 0;
@@ -533,6 +533,7 @@ int launch_slab_tb(const void* feat, int n_in, const void* w, const int* nbr, co
                            scale, shift, (const E*)residual, relu, (E*)out);
         return PVX_OK;
     } else {
-        return PVX_ERR_INVALID;
+        // the streaming kernels read the rulebook itself; from a book built for their window they take the tiles' window spans
+        return launch_slab<E, CIN, COUT, RCAP, STREAM>(feat, n_in, w, nbr, n_out, n_out_dev, bias, scale, shift, residual, relu, out, st, book);
     }
 }

@@ -129,7 +129,9 @@ class HotPathEngine:
 
     # layers that share a rulebook with enough launches to pay for its book (55 us): the five 16 -> 16 layers (bound by rulebook
     # bytes) and the four 32 -> 32 layers (the rolling kernel form needs the book's window spans a tile ahead)
-    TILEBOOK_SHAPES = {(16, 16), (16, 32), (32, 32), (64, 64)}    # (32, 64): its book form measured slower (282 vs 254 us)
+    # (32, 64): its book form measured slower (282 vs 254 us); (64, 128), (128, 128): streaming kernels, which take only the window spans
+    # from the book (PVX_ENGINE_SPAN_BOOKS=0: without)
+    TILEBOOK_SHAPES = {(16, 16), (16, 32), (32, 32), (64, 64)} | ({(64, 128), (128, 128)} if os.environ.get("PVX_ENGINE_SPAN_BOOKS", "1") != "0" else set())
 
     def _wants_tilebook(self, cin, cout):
         if self.tilebook_mode == "0":

@@ -13,7 +13,7 @@ from oracle import loader
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64)]
+SHAPES = [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)]    # the last two: streaming kernels, spans only
 
 
 def tile_blocks(book, tiles):
@@ -107,7 +107,7 @@ def test_tilebook_conv_bit_identical(cuda_device, cin, cout, sort):
         assert np.array_equal(got_ent, ent.astype(np.uint16))
         far = (ent == 0xFFFE).mean()
         # sorted rows fit the window (the 320-row window of the 128-channel form: all but a few lanes); shuffled rows mostly do not
-        assert (far == 0) if sort else (far > 0.05), far
+        assert ((far == 0) if rcap >= 384 else (far < 0.05)) if sort else (far > 0.05), far
         # the conv
         want, (scale, shift, bias) = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, residual=res)
         got, _ = run_conv(dev, feat, w, nbr_t, n_live, cin, cout, code, book=book, rcap=rcap, residual=res)
@@ -214,7 +214,7 @@ def test_tilebook_strided_rulebook_and_empty(cuda_device):
         want, _ = run_conv(dev, feat, w, nbr_t, n_live, 16, 32, 2)
         got, _ = run_conv(dev, feat, w, nbr_t, n_live, 16, 32, 2, book=book, rcap=rcap)
         assert torch.equal(got, want), live
-    assert L.pvx_tilebook_rcap(256, 256, 27, 2) == 0 and L.pvx_tilebook_rcap(128, 128, 27, 2) == 0 and L.pvx_tilebook_rcap(16, 16, 27, 0) == 0 and L.pvx_tilebook_rcap(16, 16, 9, 2) == 0
+    assert L.pvx_tilebook_rcap(256, 256, 27, 2) == 0 and L.pvx_tilebook_rcap(128, 128, 27, 2) == 320 and L.pvx_tilebook_rcap(16, 16, 27, 0) == 0 and L.pvx_tilebook_rcap(16, 16, 9, 2) == 0
     assert L.pvx_tilebook_build(None, 9, 10, None, 10, 100, None, None) == -1
 
 
